@@ -1,0 +1,690 @@
+// HBM-bound kernels of the 3dgan hot path (gfx950): batch norm, bias / activation derivatives,
+// gradient-penalty interpolation + norm, loss reductions, fused optimizer steps, Philox RNG.
+// All reductions are two-stage with a fixed summation order (deterministic, no atomics);
+// cross-lane sums use 64-wide wavefront shuffles.
+#include <stdarg.h>
+
+#include "tdg_common.h"
+
+// ---------------------------------------------------------------------------- error state
+static thread_local char g_err[512] = "";
+void tdg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* tdg_last_error(void) { return g_err; }
+extern "C" int tdg_version(void) { return 100; }
+
+#define DISPATCH_T(dtype, ...)                  \
+  if ((dtype) == TDG_BF16) {                    \
+    using T = bf16_t;                           \
+    __VA_ARGS__                                 \
+  } else if ((dtype) == TDG_F32) {              \
+    using T = float;                            \
+    __VA_ARGS__                                 \
+  } else {                                      \
+    tdg_set_error("bad dtype %d", (int)(dtype));\
+    return TDG_EINVAL;                          \
+  }
+
+static inline int ew_blocks(size_t n, int per_block = 1024) {
+  size_t b = (n + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// block-wide sum of 256 threads; result valid in thread 0
+__device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+// ============================================================================ column reductions
+// partial[blk][v][c] = sum over the block's rows of f_v(row, c), v < NV
+struct ColGeom {
+  int rows, C, cs, nblk, rows_per_blk, CL;  // CL = channel lanes (power of two <= 64)
+};
+static inline ColGeom col_geom(int rows, int C, int cs) {
+  ColGeom g;
+  g.rows = rows; g.C = C; g.cs = cs;
+  int cl = 1;
+  while (cl < C && cl < 64) cl <<= 1;
+  g.CL = cl;
+  int nblk = (rows + 127) / 128;
+  if (nblk > 256) nblk = 256;
+  if (nblk < 1) nblk = 1;
+  g.rows_per_blk = (rows + nblk - 1) / nblk;
+  g.nblk = (rows + g.rows_per_blk - 1) / g.rows_per_blk;
+  return g;
+}
+
+enum { COL_BN_STATS = 0, COL_BN_BWD = 1, COL_SUM = 2, COL_WSUM = 3 };
+
+struct ColArgs {
+  const void* x;        // primary tensor
+  const void* y;        // secondary tensor (pre for BN bwd)
+  const float* beta;    // BN beta
+  const float* coef;    // per-row coefficients (COL_WSUM)
+  int act; float leak;
+  float* partial;
+};
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const ColArgs a) {
+  __shared__ float sh[2][256];
+  const int CL = g.CL, RL = 256 / CL;
+  const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
+  const int r0 = blockIdx.x * g.rows_per_blk;
+  const int r1 = min(g.rows, r0 + g.rows_per_blk);
+  const T* x = static_cast<const T*>(a.x);
+  const T* y = static_cast<const T*>(a.y);
+  for (int c0 = 0; c0 < g.C; c0 += CL) {
+    const int c = c0 + tx;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < g.C) {
+      float pivot = 0.f, bta = 0.f;
+      if (MODE == COL_BN_STATS) pivot = to_f32<T>(x[c]);
+      if (MODE == COL_BN_BWD) bta = a.beta[c];
+      for (int r = r0 + ty; r < r1; r += RL) {
+        const size_t i = (size_t)r * g.cs + c;
+        const float v = to_f32<T>(x[i]);
+        if (MODE == COL_BN_STATS) {
+          const float d = v - pivot;
+          s0 += d; s1 += d * d;
+        } else if (MODE == COL_BN_BWD) {
+          const float pre = to_f32<T>(y[i]);
+          const float dpre = v * (a.act == TDG_ACT_RELU ? (pre > 0.f ? 1.f : 0.f)
+                                  : a.act == TDG_ACT_LRELU ? (pre > 0.f ? 1.f : a.leak) : 1.f);
+          s0 += dpre; s1 += dpre * (pre - bta);
+        } else if (MODE == COL_SUM) {
+          s0 += v;
+        } else {
+          s0 += v * (a.coef ? a.coef[r] : 1.f);
+        }
+      }
+    }
+    sh[0][threadIdx.x] = s0;
+    sh[1][threadIdx.x] = s1;
+    __syncthreads();
+    if (ty == 0 && c < g.C) {
+      float t0 = 0.f, t1 = 0.f;
+      for (int k = 0; k < RL; ++k) { t0 += sh[0][k * CL + tx]; t1 += sh[1][k * CL + tx]; }
+      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c] = t0;
+      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c] = t1;
+    }
+    __syncthreads();
+  }
+}
+
+// finalize modes
+enum { FIN_BN_STATS = 0, FIN_BN_BWD = 1, FIN_ACC = 2 };
+struct FinArgs {
+  const float* partial; int nblk, C, rows;
+  const void* x0;       // first row of the tensor (pivot) for BN stats
+  float eps;
+  float* out0;          // stats (mean | rstd)   / dbeta / dw
+  float* out1;          // bwd: mean sums [2][C] for the apply pass
+  float beta_acc;
+};
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.C) return;
+  float s0 = 0.f, s1 = 0.f;
+  for (int b = 0; b < a.nblk; ++b) {
+    s0 += a.partial[((size_t)b * 2 + 0) * a.C + c];
+    s1 += a.partial[((size_t)b * 2 + 1) * a.C + c];
+  }
+  const float inv = 1.f / (float)a.rows;
+  if (MODE == FIN_BN_STATS) {
+    const float pivot = to_f32<T>(static_cast<const T*>(a.x0)[c]);
+    const float md = s0 * inv;
+    const float var = fmaxf(s1 * inv - md * md, 0.f);
+    a.out0[c] = pivot + md;
+    a.out0[a.C + c] = rsqrtf(var + a.eps);
+  } else if (MODE == FIN_BN_BWD) {
+    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
+    a.out1[c] = s0 * inv;
+    a.out1[a.C + c] = s1 * inv;
+  } else {
+    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const T* __restrict__ u, int rows, int C, int cs,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          int act, float leak, T* __restrict__ pre, T* __restrict__ h) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float mean = stats[c], rstd = stats[C + c], b = beta[c];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const size_t i = (size_t)r * cs + c;
+      const float p = (to_f32<T>(u[i]) - mean) * rstd + b;
+      pre[i] = from_f32<T>(p);
+      h[i] = from_f32<T>(apply_act(p, act, leak));
+    }
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dh, const T* __restrict__ pre, int rows, int C,
+                                                          int cs, const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const float* __restrict__ sums, int act, float leak, T* __restrict__ du) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float rstd = stats[C + c], b = beta[c], m0 = sums[c], m1 = sums[C + c];
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+      const size_t i = (size_t)r * cs + c;
+      const float p = to_f32<T>(pre[i]);
+      const float f = act == TDG_ACT_RELU ? (p > 0.f ? 1.f : 0.f) : act == TDG_ACT_LRELU ? (p > 0.f ? 1.f : leak) : 1.f;
+      const float dpre = to_f32<T>(dh[i]) * f;
+      du[i] = from_f32<T>(rstd * (dpre - m0 - (p - b) * m1));
+    }
+  }
+}
+
+extern "C" size_t tdg_bn_workspace_bytes(int rows, int c) {
+  const ColGeom g = col_geom(rows, c, c);
+  return ((size_t)g.nblk * 2 * c + 2 * (size_t)c) * sizeof(float);
+}
+extern "C" size_t tdg_colsum_workspace_bytes(int rows, int cols) { return tdg_bn_workspace_bytes(rows, cols); }
+
+template <typename T, int MODE>
+static int run_col_partial(const ColGeom& g, const ColArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((col_partial_kernel<T, MODE>), dim3(g.nblk), dim3(256), 0, s, g, a);
+  TDG_HIP_LAUNCH_CHECK("col_partial");
+  return TDG_OK;
+}
+
+extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
+                          float leak, void* pre, void* h, float* stats, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+  TDG_CHECK_ARG(u && beta && pre && h && stats && workspace, "tdg_bn_fwd: null pointer");
+  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_fwd: bad shape rows=%d c=%d cs=%d", rows, c, cs);
+  if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_fwd: workspace too small"); return TDG_EWORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const ColGeom g = col_geom(rows, c, cs);
+  ColArgs a; memset(&a, 0, sizeof(a));
+  a.x = u; a.partial = static_cast<float*>(workspace);
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.x0 = u; f.eps = eps; f.out0 = stats;
+  const int ablocks = rows < 2048 ? rows : 2048;
+  DISPATCH_T(dtype, {
+    int rc = run_col_partial<T, COL_BN_STATS>(g, a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + 255) / 256), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(bn_fwd_apply_kernel<T>, dim3(ablocks), dim3(256), 0, s, static_cast<const T*>(u), rows, c, cs, beta,
+                       stats, act, leak, static_cast<T*>(pre), static_cast<T*>(h));
+  })
+  TDG_HIP_LAUNCH_CHECK("bn_fwd");
+  return TDG_OK;
+}
+
+extern "C" int tdg_bn_bwd(int dtype, const void* dh, const void* pre, int rows, int c, int cs, const float* beta,
+                          const float* stats, int act, float leak, void* du, float* dbeta, float beta_acc,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(dh && pre && beta && stats && du && dbeta && workspace, "tdg_bn_bwd: null pointer");
+  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_bwd: bad shape");
+  if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_bwd: workspace too small"); return TDG_EWORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const ColGeom g = col_geom(rows, c, cs);
+  ColArgs a; memset(&a, 0, sizeof(a));
+  a.x = dh; a.y = pre; a.beta = beta; a.act = act; a.leak = leak; a.partial = static_cast<float*>(workspace);
+  float* sums = a.partial + (size_t)g.nblk * 2 * c;
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.out0 = dbeta; f.out1 = sums; f.beta_acc = beta_acc;
+  const int ablocks = rows < 2048 ? rows : 2048;
+  DISPATCH_T(dtype, {
+    int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + 255) / 256), dim3(256), 0, s, f);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ablocks), dim3(256), 0, s, static_cast<const T*>(dh),
+                       static_cast<const T*>(pre), rows, c, cs, beta, stats, sums, act, leak, static_cast<T*>(du));
+  })
+  TDG_HIP_LAUNCH_CHECK("bn_bwd");
+  return TDG_OK;
+}
+
+extern "C" int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs, float* db, float beta, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(dy && db && workspace && rows > 0 && c > 0 && cs >= c, "tdg_bias_grad: bad argument");
+  if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bias_grad: workspace too small"); return TDG_EWORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const ColGeom g = col_geom(rows, c, cs);
+  ColArgs a; memset(&a, 0, sizeof(a));
+  a.x = dy; a.partial = static_cast<float*>(workspace);
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.out0 = db; f.beta_acc = beta;
+  DISPATCH_T(dtype, {
+    int rc = run_col_partial<T, COL_SUM>(g, a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + 255) / 256), dim3(256), 0, s, f);
+  })
+  TDG_HIP_LAUNCH_CHECK("bias_grad");
+  return TDG_OK;
+}
+
+extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols, int cs, const float* coef, float* dw,
+                                   float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(x && dw && workspace && rows > 0 && cols > 0 && cs >= cols, "tdg_colsum_weighted: bad argument");
+  if (workspace_bytes < tdg_bn_workspace_bytes(rows, cols)) { tdg_set_error("tdg_colsum_weighted: workspace too small"); return TDG_EWORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const ColGeom g = col_geom(rows, cols, cs);
+  ColArgs a; memset(&a, 0, sizeof(a));
+  a.x = x; a.coef = coef; a.partial = static_cast<float*>(workspace);
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = a.partial; f.nblk = g.nblk; f.C = cols; f.rows = rows; f.out0 = dw; f.beta_acc = beta;
+  DISPATCH_T(dtype, {
+    int rc = run_col_partial<T, COL_WSUM>(g, a, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + 255) / 256), dim3(256), 0, s, f);
+  })
+  TDG_HIP_LAUNCH_CHECK("colsum_weighted");
+  return TDG_OK;
+}
+
+// ============================================================================ row ops (fc2)
+template <typename T>
+__global__ void __launch_bounds__(256) rowdot_kernel(const T* __restrict__ x, int rows, int cols, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, int act, float* __restrict__ out) {
+  __shared__ float sh[4];
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* xr = x + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) s += to_f32<T>(xr[c]) * w[c];
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) out[r] = apply_act(s + (bias ? bias[0] : 0.f), act, 0.f);
+  }
+}
+
+extern "C" int tdg_rowdot(int dtype, const void* x, int rows, int cols, const float* w, const float* bias, int act,
+                          float* out, void* stream) {
+  TDG_CHECK_ARG(x && w && out && rows > 0 && cols > 0, "tdg_rowdot: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(rowdot_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(x), rows, cols, w, bias, act, out);
+  })
+  TDG_HIP_LAUNCH_CHECK("rowdot");
+  return TDG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) rowouter_kernel(const float* __restrict__ dout, const float* __restrict__ w, int rows,
+                                                      int cols, int mask_mode, float leak, const T* __restrict__ msk,
+                                                      T* __restrict__ dx) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float d = dout[r];
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const size_t i = (size_t)r * cols + c;
+      float v = d * w[c];
+      if (mask_mode != TDG_MASK_NONE) v *= mask_factor(to_f32<T>(msk[i]), mask_mode, leak);
+      dx[i] = from_f32<T>(v);
+    }
+  }
+}
+
+extern "C" int tdg_rowouter(int dtype, const float* dout, const float* w, int rows, int cols, int mask_mode, float leak,
+                            const void* mask_src, void* dx, void* stream) {
+  TDG_CHECK_ARG(dout && w && dx && rows > 0 && cols > 0, "tdg_rowouter: bad argument");
+  TDG_CHECK_ARG(mask_mode == TDG_MASK_NONE || mask_src, "tdg_rowouter: mask without mask_src");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(rowouter_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, dout, w, rows,
+                       cols, mask_mode, leak, static_cast<const T*>(mask_src), static_cast<T*>(dx));
+  })
+  TDG_HIP_LAUNCH_CHECK("rowouter");
+  return TDG_OK;
+}
+
+// ============================================================================ flat elementwise
+template <typename T>
+__global__ void __launch_bounds__(256) bias_act_kernel(const T* __restrict__ x, int rows, int C, int cs,
+                                                      const float* __restrict__ bias, int act, float leak, T* __restrict__ y) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      const size_t i = (size_t)r * cs + c;
+      y[i] = from_f32<T>(apply_act(to_f32<T>(x[i]) + (bias ? bias[c] : 0.f), act, leak));
+    }
+}
+extern "C" int tdg_bias_act(int dtype, const void* x, int rows, int c, int cs, const float* bias, int act, float leak,
+                            void* y, void* stream) {
+  TDG_CHECK_ARG(x && y && rows > 0 && c > 0 && cs >= c, "tdg_bias_act: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(bias_act_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(x), rows, c, cs, bias, act, leak, static_cast<T*>(y));
+  })
+  TDG_HIP_LAUNCH_CHECK("bias_act");
+  return TDG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) act_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ post, size_t n, int act,
+                                                     float leak, T* __restrict__ dx) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float p = to_f32<T>(post[i]);
+    float f = 1.f;
+    if (act == TDG_ACT_TANH) f = 1.f - p * p;
+    else if (act == TDG_ACT_SIGMOID) f = p * (1.f - p);
+    else if (act == TDG_ACT_LRELU) f = p > 0.f ? 1.f : leak;
+    else if (act == TDG_ACT_RELU) f = p > 0.f ? 1.f : 0.f;
+    dx[i] = from_f32<T>(to_f32<T>(dy[i]) * f);
+  }
+}
+extern "C" int tdg_act_bwd(int dtype, const void* dy, const void* post, size_t n, int act, float leak, void* dx,
+                           void* stream) {
+  TDG_CHECK_ARG(dy && post && dx && n > 0, "tdg_act_bwd: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(act_bwd_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(dy),
+                       static_cast<const T*>(post), n, act, leak, static_cast<T*>(dx));
+  })
+  TDG_HIP_LAUNCH_CHECK("act_bwd");
+  return TDG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) affine_cast_kernel(const float* __restrict__ in, size_t n, float scale, float shift,
+                                                         T* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = from_f32<T>(scale * (in[i] + shift));
+}
+extern "C" int tdg_affine_cast(int dtype, const float* in, size_t n, float scale, float shift, void* out, void* stream) {
+  TDG_CHECK_ARG(in && out && n > 0, "tdg_affine_cast: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(affine_cast_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, in, n, scale, shift,
+                       static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("affine_cast");
+  return TDG_OK;
+}
+extern "C" int tdg_cast_from_f32(int dtype, const float* in, size_t n, void* out, void* stream) {
+  return tdg_affine_cast(dtype, in, n, 1.f, 0.f, out, stream);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) cast_to_f32_kernel(const T* __restrict__ in, size_t n, float* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = to_f32<T>(in[i]);
+}
+extern "C" int tdg_cast_to_f32(int dtype, const void* in, size_t n, float* out, void* stream) {
+  TDG_CHECK_ARG(in && out && n > 0, "tdg_cast_to_f32: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(cast_to_f32_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(in),
+                       n, out);
+  })
+  TDG_HIP_LAUNCH_CHECK("cast_to_f32");
+  return TDG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) gp_interp_kernel(const T* __restrict__ x, const T* __restrict__ g,
+                                                       const float* __restrict__ alpha, int rows, int cols, T* __restrict__ xhat) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float al = alpha[r];
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      const size_t i = (size_t)r * cols + c;
+      const float xv = to_f32<T>(x[i]);
+      xhat[i] = from_f32<T>(xv + al * (to_f32<T>(g[i]) - xv));
+    }
+  }
+}
+extern "C" int tdg_gp_interp(int dtype, const void* x, const void* g, const float* alpha, int rows, int cols, void* xhat,
+                             void* stream) {
+  TDG_CHECK_ARG(x && g && alpha && xhat && rows > 0 && cols > 0, "tdg_gp_interp: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(gp_interp_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(x), static_cast<const T*>(g), alpha, rows, cols, static_cast<T*>(xhat));
+  })
+  TDG_HIP_LAUNCH_CHECK("gp_interp");
+  return TDG_OK;
+}
+
+// ---- scalar reductions -----------------------------------------------------------------------
+#define RED_BLOCKS 256
+extern "C" size_t tdg_reduce_workspace_bytes(size_t) { return RED_BLOCKS * sizeof(float); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = to_f32<T>(x[i]);
+    s += v * v;
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ void __launch_bounds__(256) reduce_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ acc,
+                                                          float beta, float scale) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) acc[0] = (beta != 0.f ? beta * acc[0] : 0.f) + scale * s;
+}
+extern "C" int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(x && acc && workspace && n > 0, "tdg_sumsq: bad argument");
+  if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_sumsq: workspace too small"); return TDG_EWORKSPACE; }
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(x),
+                       n, static_cast<float*>(workspace));
+  })
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
+                     RED_BLOCKS, acc, beta, 1.f);
+  TDG_HIP_LAUNCH_CHECK("sumsq");
+  return TDG_OK;
+}
+extern "C" int tdg_mean_f32(const float* x, int n, float* out, void* stream) {
+  TDG_CHECK_ARG(x && out && n > 0, "tdg_mean_f32: bad argument");
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out, 0.f, 1.f / (float)n);
+  TDG_HIP_LAUNCH_CHECK("mean_f32");
+  return TDG_OK;
+}
+
+__global__ void gp_scalars_kernel(const float* __restrict__ ss, float lambda, float* __restrict__ scal) {
+  const float s = sqrtf(ss[0]);
+  scal[0] = (s - 1.f) * (s - 1.f);
+  scal[1] = lambda * 2.f * (s - 1.f) / s;
+}
+extern "C" int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream) {
+  TDG_CHECK_ARG(sumsq && scal, "tdg_gp_scalars: null pointer");
+  hipLaunchKernelGGL(gp_scalars_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, lambda, scal);
+  TDG_HIP_LAUNCH_CHECK("gp_scalars");
+  return TDG_OK;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) scale_by_dev_kernel(const T* __restrict__ in, size_t n, const float* __restrict__ coef,
+                                                          T* __restrict__ out) {
+  const float k = coef[0];
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = from_f32<T>(k * to_f32<T>(in[i]));
+}
+extern "C" int tdg_scale_by_dev(int dtype, const void* in, size_t n, const float* coef, void* out, void* stream) {
+  TDG_CHECK_ARG(in && coef && out && n > 0, "tdg_scale_by_dev: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(scale_by_dev_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(in),
+                       n, coef, static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("scale_by_dev");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) fill_kernel(float* __restrict__ x, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] = v;
+}
+extern "C" int tdg_fill_f32(float* x, size_t n, float value, void* stream) {
+  TDG_CHECK_ARG(x && n > 0, "tdg_fill_f32: bad argument");
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, value);
+  TDG_HIP_LAUNCH_CHECK("fill");
+  return TDG_OK;
+}
+
+// ============================================================================ optimizers
+// 16-byte vectors; buckets are padded to a multiple of 4 floats by the host.
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, size_t n4, float lr_t, float b1, float b2, float eps,
+                                                  float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+    mv = b1 * mv + (1.f - b1) * gv;
+    vv = b2 * vv + (1.f - b2) * gv * gv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1, float beta2,
+                             float eps, float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && m && v && n > 0 && (n & 3) == 0, "tdg_adam_step: bad argument (n must be a multiple of 4)");
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr_t,
+                     beta1, beta2, eps, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("adam");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ rms,
+                                                     float* __restrict__ mom, size_t n4, float lr, float decay, float mu,
+                                                     float eps, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 rv = reinterpret_cast<f32x4*>(rms)[i], mv = reinterpret_cast<f32x4*>(mom)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+    rv = decay * rv + (1.f - decay) * gv * gv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mv[e] = mu * mv[e] + lr * gv[e] / sqrtf(rv[e] + eps);
+      pv[e] -= mv[e];
+    }
+    reinterpret_cast<f32x4*>(rms)[i] = rv;
+    reinterpret_cast<f32x4*>(mom)[i] = mv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom, size_t n, float lr, float decay,
+                                float momentum, float eps, float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && rms && mom && n > 0 && (n & 3) == 0, "tdg_rmsprop_step: bad argument");
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, rms, mom, n / 4,
+                     lr, decay, momentum, eps, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("rmsprop");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) sgdm_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc,
+                                                  size_t n4, float lr, float mu, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    f32x4 a = mu * reinterpret_cast<f32x4*>(acc)[i] + gs * reinterpret_cast<const f32x4*>(g)[i];
+    reinterpret_cast<f32x4*>(acc)[i] = a;
+    reinterpret_cast<f32x4*>(p)[i] -= lr * a;
+  }
+}
+extern "C" int tdg_sgd_momentum_step(float* p, const float* g, float* acc, size_t n, float lr, float momentum,
+                                     float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && acc && n > 0 && (n & 3) == 0, "tdg_sgd_momentum_step: bad argument");
+  hipLaunchKernelGGL(sgdm_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, acc, n / 4, lr,
+                     momentum, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("sgd_momentum");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) clamp_kernel(float* __restrict__ p, size_t n, float lo, float hi) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+extern "C" int tdg_clamp(float* p, size_t n, float lo, float hi, void* stream) {
+  TDG_CHECK_ARG(p && n > 0, "tdg_clamp: bad argument");
+  hipLaunchKernelGGL(clamp_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, n, lo, hi);
+  TDG_HIP_LAUNCH_CHECK("clamp");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) check_finite_kernel(const float* __restrict__ x, size_t n, int* __restrict__ flag) {
+  int bad = 0;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bad |= !isfinite(x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) flag[0] = 1;   // racing identical stores are benign
+}
+extern "C" int tdg_check_finite(const float* x, size_t n, int* flag, void* stream) {
+  TDG_CHECK_ARG(x && flag && n > 0, "tdg_check_finite: bad argument");
+  hipLaunchKernelGGL(check_finite_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, x, n, flag);
+  TDG_HIP_LAUNCH_CHECK("check_finite");
+  return TDG_OK;
+}
+
+// ============================================================================ Philox4x32-10
+struct Philox {
+  uint32_t c[4], k[2];
+  __device__ __forceinline__ void round() {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+    const uint32_t n0 = hi1 ^ c[1] ^ k[0], n1 = lo1, n2 = hi0 ^ c[3] ^ k[1], n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k[0] += 0x9E3779B9u; k[1] += 0xBB67AE85u;
+  }
+  __device__ __forceinline__ void gen(uint64_t seed, uint64_t stream_id, uint64_t ctr) {
+    c[0] = (uint32_t)ctr; c[1] = (uint32_t)(ctr >> 32); c[2] = (uint32_t)stream_id; c[3] = (uint32_t)(stream_id >> 32);
+    k[0] = (uint32_t)seed; k[1] = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int i = 0; i < 10; ++i) round();
+  }
+};
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1)
+
+template <typename T>
+__global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint64_t sid, uint64_t offset, size_t n, T* __restrict__ out) {
+  const size_t n4 = (n + 3) >> 2;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    Philox ph;
+    ph.gen(seed, sid, offset + i);
+    float z[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = 1.0f - u01(ph.c[2 * h]);     // (0,1]
+      const float u2 = u01(ph.c[2 * h + 1]);
+      const float r = sqrtf(-2.f * logf(u1));
+      z[2 * h] = r * cosf(6.283185307179586f * u2);
+      z[2 * h + 1] = r * sinf(6.283185307179586f * u2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < n) out[4 * i + e] = from_f32<T>(z[e]);
+  }
+}
+extern "C" int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, void* out,
+                                 void* stream) {
+  TDG_CHECK_ARG(out && n > 0, "tdg_random_normal: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(random_normal_kernel<T>, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       stream_id, offset, n, static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("random_normal");
+  return TDG_OK;
+}
+
+__global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint64_t sid, uint64_t offset, size_t n,
+                                                            float* __restrict__ out) {
+  const size_t n4 = (n + 3) >> 2;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    Philox ph;
+    ph.gen(seed, sid, offset + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < n) out[4 * i + e] = u01(ph.c[e]);
+  }
+}
+extern "C" int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out, void* stream) {
+  TDG_CHECK_ARG(out && n > 0, "tdg_random_uniform_f32: bad argument");
+  hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                     stream_id, offset, n, out);
+  TDG_HIP_LAUNCH_CHECK("random_uniform");
+  return TDG_OK;
+}

@@ -1,0 +1,58 @@
+// Implicit-GEMM kernel argument blocks shared by tdg_igemm.hip (device) and tdg_conv.cpp-side
+// planning code (host).  gfx950 only.
+#pragma once
+#include "tdg_common.h"
+
+#define IG_MAX_TAPS 32
+#define IG_MAX_CLASSES 4
+#define IG_BKB 128   // bytes of K per LDS row per main-loop step (8 x 16-byte chunks)
+
+// One output-parity class of a GEMM  C[M][N] = gather(A)[M][K] * Bp[N][K]^T.
+//   rows  m  <-> anchor (nb, a, b) on a [GH, GW] grid per image
+//   k        <-> (tap t, channel c): source pixel (a*sigma + dh[t], b*sigma + dw[t]), zero outside
+//   output pixel of row m: (a*os + oh0, b*os + ow0)
+struct IgClass {
+  int M, GH, GW, ntaps;
+  int K;                 // ntaps * C (logical K, elements)
+  int nsteps;            // ceil(K / (IG_BKB / sizeof(T)))
+  int Kp;                // packed filter row pitch (elements) = nsteps * BKE
+  int oh0, ow0;
+  unsigned w_off_bytes;  // this class's packed filter block inside the packed buffer
+  FastDiv fd_ghw, fd_gw;
+  short tap[IG_MAX_TAPS];  // (dh & 0xff) | ((dw & 0xff) << 8), signed bytes
+};
+
+struct IgArgs {
+  const void* src;
+  const void* wpack;
+  const float* bias;
+  void* out;
+  const void* mask_src;
+  unsigned src_bytes, w_bytes;
+  int SH, SW, sigma;
+  int C, Cs;             // channels per tap in K (effective, multiple of VEC on the vector path), channel stride
+  FastDiv fd_c;          // divide by C (scalar path) or by C/VEC (vector path)
+  int N, OH, OW, os, Cso;
+  int act, mask_mode;
+  float leak;
+  int ntiles_n, ntiles_m_max, nclasses;
+  IgClass cls[IG_MAX_CLASSES];
+};
+
+// Filter-gradient GEMM  out[(t,c)][n] = sum_m gather(A)[m][(t,c)] * G[m][n], split over m.
+struct WgArgs {
+  const void* src;       // gathered operand (big-side tensor)
+  const void* g;         // dense rows [M][Gs] (small-side tensor)
+  float* slabs;          // [nsplit][ntaps*Clog][N] f32 partials
+  unsigned src_bytes, g_bytes;
+  int M, GH, GW, SH, SW, sigma;
+  int C, Clog, Cs, ntaps;  // effective / logical channels per tap, channel stride
+  int KK;                  // ntaps * C
+  FastDiv fd_c, fd_ghw, fd_gw;
+  int N, Gs;               // G channels (effective), row pitch
+  int Nlog;                // logical N written to the slabs
+  int nsplit, m_per_split; // m_per_split is a multiple of the step's row count
+  long long slab_stride;   // elements
+  int ntiles_n, ntiles_k;
+  short tap[IG_MAX_TAPS];
+};

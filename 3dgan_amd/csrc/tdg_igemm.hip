@@ -1,0 +1,1001 @@
+// Implicit-GEMM convolution kernels for gfx950 (CDNA4): conv2d forward, conv2d_backprop_input
+// (= conv2d_transpose) and conv2d_backprop_filter of the reference's conv stack
+// (ops/layers.py:101,142 and the autodiff ops TF derives from them).
+//
+// Design:
+//  * 64-wide waves, 4 waves per workgroup, v_mfma_f32_16x16x32_bf16 (bf16) or
+//    v_mfma_f32_16x16x4_f32 (exact f32 parity path); f32 accumulators.
+//  * NHWC activations: the im2col gather is a 16-byte vector load per (pixel, 8 channels)
+//    through a buffer descriptor, so SAME-padding taps are out-of-range offsets that read 0.
+//  * Operands are staged through LDS in 128-byte K rows with an XOR swizzle that makes every
+//    ds_read_b128 fragment read conflict-free (chunk ^= (row >> 1) & 7).
+//  * MFMA operands are swapped (filter rows first) so each lane ends up owning 4 consecutive
+//    output channels of one pixel: the epilogue (bias, activation, derivative mask) stores
+//    8/16-byte vectors.
+//  * Backward-data runs as `stride^2` output-parity classes of stride-1 gathers (blockIdx.z),
+//    each with its own tap subset and packed filter block: no zero-stuffed MACs.
+//  * Filter gradient: both operands are transposed on the way out of LDS
+//    (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32), rows split over blockIdx.z into f32
+//    slabs that a second kernel sums in a fixed order (deterministic, no atomics).
+#include "tdg_igemm.h"
+
+#define OOB_OFFSET 0xFFFFFF00u
+
+template <typename T>
+struct Mma;
+template <>
+struct Mma<bf16_t> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ void run(f32x4& acc, const frag& a, const frag& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  }
+};
+template <>
+struct Mma<float> {
+  using frag = f32x4;
+  static __device__ __forceinline__ void run(f32x4& acc, const frag& a, const frag& b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
+  }
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+template <typename T>
+__device__ __forceinline__ T buffer_load_elem(__amdgpu_buffer_rsrc_t r, unsigned off);
+template <>
+__device__ __forceinline__ float buffer_load_elem<float>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+template <>
+__device__ __forceinline__ bf16_t buffer_load_elem<bf16_t>(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(bf16_t, __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+}
+
+__device__ __forceinline__ int tap_dh(int pk) { return (pk << 24) >> 24; }
+__device__ __forceinline__ int tap_dw(int pk) { return (pk << 16) >> 24; }
+
+// swizzled byte address of 16-byte chunk `chunk` of row `row` in a [rows][128 B] LDS tile
+__device__ __forceinline__ int lds_swz(int row, int chunk) {
+  return row * IG_BKB + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+// ============================================================================================
+// forward-type implicit GEMM: conv2d fwd, conv2d bwd-data (parity classes), dense
+// ============================================================================================
+template <typename T, int BM, int BN, int WGM, int WGN, bool VECA>
+__global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BKE = IG_BKB / (int)sizeof(T);
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int NA = BM / 32;              // A vectors per thread per step (vector path)
+  constexpr int NB = (BN + 31) / 32;       // B vectors per thread per step
+  static_assert(WGM * WGN == 4 && WM % 16 == 0 && WN % 16 == 0 && BM % 32 == 0, "tile config");
+  using Frag = typename Mma<T>::frag;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sB = smem + BM * IG_BKB;
+  int* sTap = reinterpret_cast<int*>(smem + (BM + BN) * IG_BKB);
+
+  const IgClass& cl = args.cls[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / args.ntiles_n;
+  const int tile_n = bid - tile_m * args.ntiles_n;
+  const int M = cl.M;
+  if (tile_m * BM >= M) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = cl.ntaps;
+  const int SH = args.SH, SW = args.SW, Cs = args.Cs;
+
+  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
+  const __amdgpu_buffer_rsrc_t rB =
+      make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, args.w_bytes - cl.w_off_bytes);
+
+  // ---- per-thread row bookkeeping (vector path: chunk column fixed, NA rows) ----------------
+  const int ch = tid & 7;
+  const int rsub = tid >> 3;
+  int a_h[NA], a_w[NA];
+  unsigned a_base[NA];
+  if constexpr (VECA) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int m = m0 + rsub + 32 * i;
+      const bool ok = m < M;
+      const unsigned mm = ok ? (unsigned)m : 0u;
+      const unsigned nb = fd_div(mm, cl.fd_ghw);
+      const unsigned rem = mm - nb * (unsigned)(cl.GH * cl.GW);
+      const unsigned a = fd_div(rem, cl.fd_gw);
+      const unsigned b = rem - a * (unsigned)cl.GW;
+      a_h[i] = ok ? (int)a * args.sigma : -(1 << 20);
+      a_w[i] = (int)b * args.sigma;
+      a_base[i] = ((nb * (unsigned)SH + a * (unsigned)args.sigma) * (unsigned)SW + b * (unsigned)args.sigma) * (unsigned)Cs;
+    }
+  }
+  // k decomposition of this thread's chunk column: kv = step*8 + ch -> (tap, cvec)
+  const int CV = (int)args.fd_c.d;  // vectors per tap (vector path) / channels per tap (scalar path)
+  int k_tap = 0, k_cv = 0;
+  if constexpr (VECA) {
+    k_tap = (int)fd_div((unsigned)ch, args.fd_c);
+    k_cv = ch - k_tap * CV;
+  }
+
+  i32x4 ra[NA], rb[NB];
+
+  auto load_tiles = [&](int step) {
+    if constexpr (VECA) {
+      const bool t_ok = k_tap < ntaps;
+      const int pk = sTap[t_ok ? k_tap : 0];
+      const int dh = tap_dh(pk), dw = tap_dw(pk);
+      const int koff = (dh * SW + dw) * Cs + k_cv * VEC;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int ih = a_h[i] + dh, iw = a_w[i] + dw;
+        const bool ok = t_ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+        const unsigned off = ok ? (a_base[i] + (unsigned)koff) * (unsigned)sizeof(T) : OOB_OFFSET;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0);
+      }
+      k_cv += 8;
+      while (k_cv >= CV) {
+        k_cv -= CV;
+        ++k_tap;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int rbn = rsub + 32 * j;
+      const int n = n0 + rbn;
+      const bool ok = (rbn < BN) && (n < args.N);
+      const unsigned off =
+          ok ? ((unsigned)n * (unsigned)cl.Kp + (unsigned)(step * BKE + ch * VEC)) * (unsigned)sizeof(T) : OOB_OFFSET;
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rB, off, 0, 0);
+    }
+  };
+
+  auto store_tiles = [&]() {
+    if constexpr (VECA) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<i32x4*>(sA + lds_swz(rsub + 32 * i, ch)) = ra[i];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int rbn = rsub + 32 * j;
+      if (rbn < BN) *reinterpret_cast<i32x4*>(sB + lds_swz(rbn, ch)) = rb[j];
+    }
+  };
+
+  // scalar gather for thin-channel sources (C in {1,3,4,...}): element-by-element, no prefetch
+  auto gather_scalar = [&](int step) {
+    constexpr int RPT = BM * BKE / 256;   // elements per thread
+    constexpr int RSTEP = 256 / BKE;      // row stride between a thread's elements
+    const int kcol = tid % BKE;
+    const int k = step * BKE + kcol;
+    const bool k_ok = k < cl.K;
+    const unsigned tap = fd_div((unsigned)(k_ok ? k : 0), args.fd_c);
+    const int c = (k_ok ? k : 0) - (int)tap * CV;
+    const int pk = sTap[tap];
+    const int dh = tap_dh(pk), dw = tap_dw(pk);
+    const int bcol = kcol * (int)sizeof(T);
+#pragma unroll 4
+    for (int i = 0; i < RPT; ++i) {
+      const int row = tid / BKE + RSTEP * i;
+      const int m = m0 + row;
+      const bool okm = m < M;
+      const unsigned mm = okm ? (unsigned)m : 0u;
+      const unsigned nb = fd_div(mm, cl.fd_ghw);
+      const unsigned rem = mm - nb * (unsigned)(cl.GH * cl.GW);
+      const unsigned a = fd_div(rem, cl.fd_gw);
+      const unsigned b = rem - a * (unsigned)cl.GW;
+      const int ih = (int)a * args.sigma + dh, iw = (int)b * args.sigma + dw;
+      const bool ok = okm && k_ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+      const unsigned off =
+          ok ? (((nb * (unsigned)SH + (unsigned)ih) * (unsigned)SW + (unsigned)iw) * (unsigned)Cs + (unsigned)c) *
+                   (unsigned)sizeof(T)
+             : OOB_OFFSET;
+      const T v = buffer_load_elem<T>(rA, off);
+      *reinterpret_cast<T*>(sA + lds_swz(row, bcol >> 4) + (bcol & 15)) = v;
+    }
+  };
+
+  // ---- wave / lane roles ------------------------------------------------------------------------
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WGN, wn = wave - wm * WGN;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int swl = (r16 >> 1) & 7;                       // swizzle term (tile bases are multiples of 16 rows)
+  const char* pA = sA + (wm * WM + r16) * IG_BKB;
+  const char* pB = sB + (wn * WN + r16) * IG_BKB;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = cl.nsteps;
+  load_tiles(0);
+  for (int step = 0; step < nsteps; ++step) {
+    store_tiles();
+    if constexpr (!VECA) gather_scalar(step);
+    __syncthreads();
+    if (step + 1 < nsteps) load_tiles(step + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int coff = ((ks * 4 + q) ^ swl) << 4;
+      Frag fa[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const Frag*>(pA + i * 16 * IG_BKB + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const Frag fb = *reinterpret_cast<const Frag*>(pB + j * 16 * IG_BKB + coff);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) Mma<T>::run(acc[i][j], fb, fa[i]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel (r16) x 4 consecutive channels (q*4..) per 16x16 tile ----------
+  const int N = args.N, Cso = args.Cso;
+  const bool vec_ok = ((N & 3) == 0) && ((Cso & 3) == 0);
+  T* out = static_cast<T*>(args.out);
+  const T* msk = static_cast<const T*>(args.mask_src);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WM + i * 16 + r16;
+    if (m >= M) continue;
+    const unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
+    const unsigned rem = (unsigned)m - nb * (unsigned)(cl.GH * cl.GW);
+    const unsigned a = fd_div(rem, cl.fd_gw);
+    const unsigned b = rem - a * (unsigned)cl.GW;
+    const size_t pix = ((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
+                        b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)Cso;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + q * 4;
+      if (n >= N) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (vec_ok) {
+        if (args.bias) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(args.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bv[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], args.act, args.leak);
+        if (args.mask_mode != TDG_MASK_NONE) {
+          if constexpr (sizeof(T) == 4) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(msk + pix + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mask_factor(mv[e], args.mask_mode, args.leak);
+          } else {
+            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + pix + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mask_factor((float)mv[e], args.mask_mode, args.leak);
+          }
+        }
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(out + pix + n) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+          *reinterpret_cast<bf16x4*>(out + pix + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < N) {
+            float x = v[e] + (args.bias ? args.bias[n + e] : 0.f);
+            x = apply_act(x, args.act, args.leak);
+            if (args.mask_mode != TDG_MASK_NONE) x *= mask_factor(to_f32<T>(msk[pix + n + e]), args.mask_mode, args.leak);
+            out[pix + n + e] = from_f32<T>(x);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================================
+// filter gradient: slabs[z][(t,c)][n] = sum over this split's rows of gather(A)[m][(t,c)] * G[m][n]
+// ============================================================================================
+template <typename T>
+struct WgGeom;
+template <>
+struct WgGeom<bf16_t> {
+  static constexpr int MR = 64;   // reduction rows per step (2 x k32)
+  static __host__ __device__ constexpr int pitch(int cols) { return ((cols * 2 + 255) / 256) * 256 + 32; }
+};
+template <>
+struct WgGeom<float> {
+  static constexpr int MR = 32;   // 8 x k4
+  static __host__ __device__ constexpr int pitch(int cols) { return (cols * 4) % 128 == 64 ? cols * 4 : cols * 4 + 64; }
+};
+
+// byte offset inside an LDS slab row for the transposed-read layouts
+template <typename T>
+__device__ __forceinline__ int slab_off(int row, int colbyte, int pitch) {
+  if constexpr (sizeof(T) == 2) return row * pitch + (colbyte ^ (((row >> 3) & 1) << 7));
+  return row * pitch + colbyte;
+}
+
+template <typename T, int BKK, int BN, int WGK, int WGN, bool VECA>
+__global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const WgArgs args) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int MR = WgGeom<T>::MR;
+  constexpr int PA = WgGeom<T>::pitch(BKK), PG = WgGeom<T>::pitch(BN);
+  constexpr int WK = BKK / WGK, WN = BN / WGN;
+  constexpr int TK = WK / 16, TN = WN / 16;
+  constexpr int AVR = BKK / VEC;            // A vectors per slab row
+  constexpr int GVR = BN / VEC;             // G vectors per slab row
+  constexpr int NAV = MR * AVR / 256;       // A vectors per thread per step
+  constexpr int NGV = (MR * GVR + 255) / 256;
+  static_assert(WGK * WGN == 4 && WK % 16 == 0 && WN % 16 == 0 && (MR * AVR) % 256 == 0 && 256 % AVR == 0, "tile config");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sG = smem + MR * PA;
+  int* sTap = reinterpret_cast<int*>(smem + MR * PA + MR * PG);
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = bid / args.ntiles_n;
+  const int tile_n = bid - tile_k * args.ntiles_n;
+  const int kk0 = tile_k * BKK, n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int m_begin = split * args.m_per_split;
+  const int m_end = min(args.M, m_begin + args.m_per_split);
+  const int SH = args.SH, SW = args.SW, Cs = args.Cs;
+
+  if (tid < IG_MAX_TAPS) sTap[tid] = args.tap[tid];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(args.g, args.g_bytes);
+
+  // ---- A gather: this thread's kk column is fixed for the whole kernel -----------------------
+  const int avc = tid % AVR;                 // vector column
+  const int arow0 = tid / AVR;               // first row; rows step by 256/AVR
+  constexpr int ARS = 256 / AVR;
+  int a_dh = 0, a_dw = 0, a_koff = 0;
+  bool a_kok = false;
+  if constexpr (VECA) {
+    const int kv = (kk0 / VEC) + avc;
+    const int CV = (int)args.fd_c.d;
+    const int tap = (int)fd_div((unsigned)kv, args.fd_c);
+    const int cv = kv - tap * CV;
+    a_kok = tap < args.ntaps;
+    const int pk = sTap[a_kok ? tap : 0];
+    a_dh = tap_dh(pk);
+    a_dw = tap_dw(pk);
+    a_koff = (a_dh * SW + a_dw) * Cs + cv * VEC;
+  }
+
+  i32x4 ra[NAV], rg[NGV];
+
+  auto load_slabs = [&](int mstep) {
+    if constexpr (VECA) {
+#pragma unroll
+      for (int i = 0; i < NAV; ++i) {
+        const int m = mstep + arow0 + ARS * i;
+        const bool okm = m < m_end;
+        const unsigned mm = okm ? (unsigned)m : 0u;
+        const unsigned nb = fd_div(mm, args.fd_ghw);
+        const unsigned rem = mm - nb * (unsigned)(args.GH * args.GW);
+        const unsigned a = fd_div(rem, args.fd_gw);
+        const unsigned b = rem - a * (unsigned)args.GW;
+        const int ih = (int)a * args.sigma + a_dh, iw = (int)b * args.sigma + a_dw;
+        const bool ok = okm && a_kok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+        const unsigned base = ((nb * (unsigned)SH + a * (unsigned)args.sigma) * (unsigned)SW + b * (unsigned)args.sigma) * (unsigned)Cs;
+        const unsigned off = ok ? (base + (unsigned)a_koff) * (unsigned)sizeof(T) : OOB_OFFSET;
+        ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+      const int v = tid + 256 * i;
+      const int row = v / GVR, col = v - row * GVR;
+      const int m = mstep + row;
+      const int n = n0 + col * VEC;
+      const bool ok = (v < MR * GVR) && (m < m_end) && (n < args.N);
+      const unsigned off = ok ? ((unsigned)m * (unsigned)args.Gs + (unsigned)n) * (unsigned)sizeof(T) : OOB_OFFSET;
+      rg[i] = __builtin_amdgcn_raw_buffer_load_b128(rG, off, 0, 0);
+    }
+  };
+
+  auto store_slabs = [&]() {
+    if constexpr (VECA) {
+#pragma unroll
+      for (int i = 0; i < NAV; ++i)
+        *reinterpret_cast<i32x4*>(sA + slab_off<T>(arow0 + ARS * i, avc * 16, PA)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NGV; ++i) {
+      const int v = tid + 256 * i;
+      const int row = v / GVR, col = v - row * GVR;
+      if (v < MR * GVR) *reinterpret_cast<i32x4*>(sG + slab_off<T>(row, col * 16, PG)) = rg[i];
+    }
+  };
+
+  auto gather_scalar = [&](int mstep) {
+    constexpr int RPT = MR * BKK / 256;
+    constexpr int RSTEP = 256 / BKK > 0 ? 256 / BKK : 1;
+    static_assert(256 % BKK == 0 || BKK % 256 == 0, "scalar gather mapping");
+    const int col = tid % BKK;
+    const int kk = kk0 + col;
+    const bool k_ok = kk < args.KK;
+    const int CV = (int)args.fd_c.d;
+    const unsigned tap = fd_div((unsigned)(k_ok ? kk : 0), args.fd_c);
+    const int c = (k_ok ? kk : 0) - (int)tap * CV;
+    const int pk = sTap[tap];
+    const int dh = tap_dh(pk), dw = tap_dw(pk);
+#pragma unroll 4
+    for (int i = 0; i < RPT; ++i) {
+      const int row = tid / BKK + RSTEP * i;
+      const int m = mstep + row;
+      const bool okm = m < m_end;
+      const unsigned mm = okm ? (unsigned)m : 0u;
+      const unsigned nb = fd_div(mm, args.fd_ghw);
+      const unsigned rem = mm - nb * (unsigned)(args.GH * args.GW);
+      const unsigned a = fd_div(rem, args.fd_gw);
+      const unsigned b = rem - a * (unsigned)args.GW;
+      const int ih = (int)a * args.sigma + dh, iw = (int)b * args.sigma + dw;
+      const bool ok = okm && k_ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+      const unsigned off =
+          ok ? (((nb * (unsigned)SH + (unsigned)ih) * (unsigned)SW + (unsigned)iw) * (unsigned)Cs + (unsigned)c) *
+                   (unsigned)sizeof(T)
+             : OOB_OFFSET;
+      const T v = buffer_load_elem<T>(rA, off);
+      *reinterpret_cast<T*>(sA + slab_off<T>(row, col * (int)sizeof(T), PA)) = v;
+    }
+  };
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wk = wave / WGN, wn = wave - wk * WGN;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  f32x4 acc[TK][TN];
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  using Frag = typename Mma<T>::frag;
+  load_slabs(m_begin);
+  for (int mstep = m_begin; mstep < m_end; mstep += MR) {
+    store_slabs();
+    if constexpr (!VECA) gather_scalar(mstep);
+    __syncthreads();
+    if (mstep + MR < m_end) load_slabs(mstep + MR);
+    if constexpr (sizeof(T) == 2) {
+      // transposed fragments: lane (r16, q) wants slab[ks*32 + 8q + j][col0 + r16], j = 0..7
+#pragma unroll
+      for (int ks = 0; ks < MR / 32; ++ks) {
+        const int rrow = ks * 32 + 8 * q + (r16 >> 2);
+        const int rcol = (r16 & 3) * 4;
+        Frag fa[TK];
+#pragma unroll
+        for (int i = 0; i < TK; ++i) {
+          const int colb = (wk * WK + i * 16 + rcol) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(sA + slab_off<T>(rrow, colb, PA)));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(sA + slab_off<T>(rrow + 4, colb, PA)));
+          fa[i] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int colb = (wn * WN + j * 16 + rcol) * 2;
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(sG + slab_off<T>(rrow, colb, PG)));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+              (__attribute__((address_space(3))) bf16x4*)(sG + slab_off<T>(rrow + 4, colb, PG)));
+          const Frag fg = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int i = 0; i < TK; ++i) Mma<T>::run(acc[i][j], fg, fa[i]);
+        }
+      }
+    } else {
+      // f32: one k4 MFMA per 4 slab rows; lane (r16, q) reads slab[4e + q][col0 + r16]
+#pragma unroll
+      for (int e = 0; e < MR / 4; ++e) {
+        const int rrow = 4 * e + q;
+        float fa[TK];
+#pragma unroll
+        for (int i = 0; i < TK; ++i)
+          fa[i] = *reinterpret_cast<const float*>(sA + rrow * PA + (wk * WK + i * 16 + r16) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const float fg = *reinterpret_cast<const float*>(sG + rrow * PG + (wn * WN + j * 16 + r16) * 4);
+#pragma unroll
+          for (int i = 0; i < TK; ++i)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fg, fa[i], acc[i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns filter row kk (r16) x 4 consecutive n ----------------------------------
+  float* slab = args.slabs + (size_t)split * (size_t)args.slab_stride;
+  const int CV = (int)args.fd_c.d;
+  const int Ceff = VECA ? CV * VEC : CV;
+#pragma unroll
+  for (int i = 0; i < TK; ++i) {
+    const int kk = kk0 + wk * WK + i * 16 + r16;
+    if (kk >= args.KK) continue;
+    const int tap = kk / Ceff;
+    const int c = kk - tap * Ceff;
+    if (c >= args.Clog) continue;
+    float* rowp = slab + ((size_t)tap * args.Clog + c) * (size_t)args.Nlog;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 16 + q * 4;
+      if (n + 3 < args.Nlog && (args.Nlog & 3) == 0) {
+        *reinterpret_cast<f32x4*>(rowp + n) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < args.Nlog) rowp[n + e] = acc[i][j][e];
+      }
+    }
+  }
+}
+
+// dw[i] = beta*dw[i] + sum_z slabs[z][i]   (fixed summation order)
+__global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                         size_t n, int nsplit, size_t stride, float beta) {
+  const size_t n4 = n >> 2;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
+    for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * stride + 4 * i);
+    if (beta != 0.f) s += beta * *reinterpret_cast<const f32x4*>(dw + 4 * i);
+    *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = (n4 << 2) + threadIdx.x;
+    float s = slabs[i];
+    for (int z = 1; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
+    if (beta != 0.f) s += beta * dw[i];
+    dw[i] = s;
+  }
+}
+
+// ============================================================================================
+// filter packing: f32 master [taps][Cdim][Kdim] -> packed [rows][Kp] (dtype T), zero padded
+//   element (row r, tap index ti, channel c) = w[tap_ids[ti] * stride_tap + r*stride_row + c*stride_ch]
+// ============================================================================================
+struct PackArgs {
+  const float* w;
+  void* out;
+  int rows, ntaps, C, Ceff, Kp;
+  int stride_tap, stride_row, stride_ch;
+  int tap_ids[IG_MAX_TAPS];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
+  // one block per (row tile of 32, k tile of 32) with an LDS transpose so both sides coalesce
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const bool row_fast = a.stride_row == 1;                  // which source index is contiguous
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int i = ty + 8 * p;
+    // source read: if rows are contiguous, lanes walk rows; else lanes walk k (channels)
+    const int r = row_fast ? r0 + tx : r0 + i;
+    const int k = row_fast ? k0 + i : k0 + tx;
+    float v = 0.f;
+    if (r < a.rows && k < a.ntaps * a.Ceff) {
+      const int ti = k / a.Ceff, c = k - ti * a.Ceff;
+      if (c < a.C) v = a.w[(size_t)a.tap_ids[ti] * a.stride_tap + (size_t)r * a.stride_row + (size_t)c * a.stride_ch];
+    }
+    if (row_fast) tile[i][tx] = v; else tile[tx][i] = v;   // tile[k_local][r_local]
+  }
+  __syncthreads();
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int rl = ty + 8 * p;
+    const int r = r0 + rl, k = k0 + tx;
+    if (r < a.rows && k < a.Kp) out[(size_t)r * a.Kp + k] = from_f32<T>(tile[tx][rl]);
+  }
+}
+
+// ============================================================================================
+// host side: planning + launch
+// ============================================================================================
+namespace {
+
+struct TileCfg { int bm, bn; };
+
+inline int pick_bn(int n) {
+  if (n <= 16) return 16;
+  if (n <= 64) return 64;
+  const double w128 = (double)tdg_round_up(n, 128) / n, w208 = (double)tdg_round_up(n, 208) / n;
+  return w208 < w128 - 1e-9 ? 208 : 128;
+}
+
+template <typename T, int BM, int BN, int WGM, int WGN>
+int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStream_t s) {
+  const size_t lds = (size_t)(BM + BN) * IG_BKB + IG_MAX_TAPS * sizeof(int);
+  dim3 grid(grid_x, 1, nclasses), block(256);
+  if (veca)
+    hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, true>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, false>), grid, block, lds, s, a);
+  TDG_HIP_LAUNCH_CHECK("igemm_fwd");
+  return TDG_OK;
+}
+
+template <typename T>
+int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
+  constexpr int BM = 128;
+  int mmax = 0;
+  for (int c = 0; c < a.nclasses; ++c) mmax = a.cls[c].M > mmax ? a.cls[c].M : mmax;
+  a.ntiles_n = tdg_ceil_div(a.N, bn);
+  a.ntiles_m_max = tdg_ceil_div(mmax, BM);
+  const int gx = a.ntiles_n * a.ntiles_m_max;
+  switch (bn) {
+    case 16: return launch_fwd_cfg<T, BM, 16, 4, 1>(a, veca, gx, a.nclasses, s);
+    case 64: return launch_fwd_cfg<T, BM, 64, 4, 1>(a, veca, gx, a.nclasses, s);
+    case 128: return launch_fwd_cfg<T, BM, 128, 2, 2>(a, veca, gx, a.nclasses, s);
+    case 208: return launch_fwd_cfg<T, BM, 208, 4, 1>(a, veca, gx, a.nclasses, s);
+  }
+  tdg_set_error("igemm_fwd: no tile config for BN=%d", bn);
+  return TDG_EUNSUPPORTED;
+}
+
+template <typename T, int BKK, int BN, int WGK, int WGN>
+int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
+  constexpr int MR = WgGeom<T>::MR;
+  const size_t lds = (size_t)MR * (WgGeom<T>::pitch(BKK) + WgGeom<T>::pitch(BN)) + IG_MAX_TAPS * sizeof(int);
+  dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(256);
+  if (veca)
+    hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, true>), grid, block, lds, s, a);
+  else
+    hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, false>), grid, block, lds, s, a);
+  TDG_HIP_LAUNCH_CHECK("igemm_wgrad");
+  return TDG_OK;
+}
+
+template <typename T>
+int launch_wgrad(WgArgs& a, bool veca, int bn, hipStream_t s) {
+  switch (bn) {
+    case 16: return launch_wgrad_cfg<T, 128, 16, 4, 1>(a, veca, s);
+    case 64: return launch_wgrad_cfg<T, 128, 64, 4, 1>(a, veca, s);
+    case 128: return launch_wgrad_cfg<T, 128, 128, 2, 2>(a, veca, s);
+    case 208: return launch_wgrad_cfg<T, 128, 208, 4, 1>(a, veca, s);
+  }
+  tdg_set_error("igemm_wgrad: no tile config for BN=%d", bn);
+  return TDG_EUNSUPPORTED;
+}
+
+inline short pack_tap(int dh, int dw) { return (short)((dh & 0xff) | ((dw & 0xff) << 8)); }
+
+int validate_desc(const TdgConvDesc* d, const char* who) {
+  TDG_CHECK_ARG(d != nullptr, "%s: null descriptor", who);
+  TDG_CHECK_ARG(d->dtype == TDG_F32 || d->dtype == TDG_BF16, "%s: bad dtype %d", who, d->dtype);
+  TDG_CHECK_ARG(d->n > 0 && d->h > 0 && d->w > 0 && d->c > 0 && d->oh > 0 && d->ow > 0 && d->k > 0, "%s: non-positive dims", who);
+  TDG_CHECK_ARG(d->cs >= d->c && d->ks >= d->k, "%s: channel stride smaller than channels", who);
+  TDG_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= IG_MAX_TAPS, "%s: filter %dx%d unsupported (max %d taps)", who, d->kh, d->kw, IG_MAX_TAPS);
+  TDG_CHECK_ARG(d->stride >= 1 && d->stride <= 2, "%s: stride %d unsupported", who, d->stride);
+  TDG_CHECK_ARG(d->pad_t >= 0 && d->pad_l >= 0 && d->pad_t < 128 && d->pad_l < 128, "%s: bad padding", who);
+  // every output pixel's window must start inside the padded input
+  TDG_CHECK_ARG((d->oh - 1) * d->stride - d->pad_t < d->h && (d->ow - 1) * d->stride - d->pad_l < d->w, "%s: output larger than the input admits", who);
+  const long long big = (long long)d->n * d->h * d->w * d->cs * tdg_dtype_size(d->dtype);
+  const long long small = (long long)d->n * d->oh * d->ow * d->ks * tdg_dtype_size(d->dtype);
+  TDG_CHECK_ARG(big < 0xFFFFFF00ll && small < 0xFFFFFF00ll, "%s: tensor exceeds the 4 GiB buffer-descriptor range", who);
+  return TDG_OK;
+}
+
+// effective channel count of a tensor side for the vector gather (0 -> scalar path)
+inline int eff_channels(int c, int cs, int vec) { return (cs % vec == 0 && cs - c < vec) ? cs : 0; }
+
+struct BwdClassPlan {
+  int ntaps;
+  int tap_ids[IG_MAX_TAPS];
+  int dh[IG_MAX_TAPS], dw[IG_MAX_TAPS];
+  int GH, GW, oh0, ow0;
+};
+
+// parity classes of conv2d_backprop_input: output (big-side) pixel ih = s*a + ph takes taps
+// kh == (ph + pad_t) mod s, reading small-side row a + (ph + pad_t - kh)/s.
+int plan_bwd_classes(const TdgConvDesc* d, BwdClassPlan* cls) {
+  const int s = d->stride;
+  int nc = 0;
+  for (int ph = 0; ph < s; ++ph)
+    for (int pw = 0; pw < s; ++pw) {
+      BwdClassPlan& c = cls[nc++];
+      c.oh0 = ph;
+      c.ow0 = pw;
+      c.GH = (d->h - ph + s - 1) / s;
+      c.GW = (d->w - pw + s - 1) / s;
+      c.ntaps = 0;
+      for (int kh = 0; kh < d->kh; ++kh) {
+        if ((ph + d->pad_t - kh) % s != 0) continue;
+        for (int kw = 0; kw < d->kw; ++kw) {
+          if ((pw + d->pad_l - kw) % s != 0) continue;
+          c.tap_ids[c.ntaps] = kh * d->kw + kw;
+          c.dh[c.ntaps] = (ph + d->pad_t - kh) / s;
+          c.dw[c.ntaps] = (pw + d->pad_l - kw) / s;
+          ++c.ntaps;
+        }
+      }
+    }
+  return nc;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t tdg_packed_filter_fwd_bytes(const TdgConvDesc* d) {
+  if (validate_desc(d, "tdg_packed_filter_fwd_bytes") != TDG_OK) return 0;
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  int ce = eff_channels(d->c, d->cs, vec);
+  if (!ce) ce = d->c;
+  const long long K = (long long)d->kh * d->kw * ce;
+  return (size_t)d->k * (size_t)tdg_round_up(K, bke) * es;
+}
+
+size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d) {
+  if (validate_desc(d, "tdg_packed_filter_bwd_bytes") != TDG_OK) return 0;
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  int ke = eff_channels(d->k, d->ks, vec);
+  if (!ke) ke = d->k;
+  BwdClassPlan cls[IG_MAX_CLASSES];
+  const int nc = plan_bwd_classes(d, cls);
+  size_t total = 0;
+  for (int i = 0; i < nc; ++i) total += (size_t)d->c * (size_t)tdg_round_up((long long)cls[i].ntaps * ke, bke) * es;
+  return total;
+}
+
+int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
+  int rc = validate_desc(d, "tdg_pack_filter_fwd");
+  if (rc) return rc;
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  int ce = eff_channels(d->c, d->cs, vec);
+  if (!ce) ce = d->c;
+  PackArgs a;
+  a.w = w;
+  a.out = packed;
+  a.rows = d->k;
+  a.ntaps = d->kh * d->kw;
+  a.C = d->c;
+  a.Ceff = ce;
+  a.Kp = (int)tdg_round_up((long long)a.ntaps * ce, bke);
+  a.stride_tap = d->c * d->k;
+  a.stride_row = 1;       // row = small-side channel (last master index)
+  a.stride_ch = d->k;     // K channel = big-side channel
+  for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = t;
+  dim3 grid(tdg_ceil_div(a.Kp, 32), tdg_ceil_div(a.rows, 32));
+  if (d->dtype == TDG_BF16)
+    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  TDG_HIP_LAUNCH_CHECK("pack_filter_fwd");
+  return TDG_OK;
+}
+
+int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
+  int rc = validate_desc(d, "tdg_pack_filter_bwd");
+  if (rc) return rc;
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  int ke = eff_channels(d->k, d->ks, vec);
+  if (!ke) ke = d->k;
+  BwdClassPlan cls[IG_MAX_CLASSES];
+  const int nc = plan_bwd_classes(d, cls);
+  size_t off = 0;
+  for (int i = 0; i < nc; ++i) {
+    if (cls[i].ntaps == 0) continue;
+    PackArgs a;
+    a.w = w;
+    a.out = static_cast<char*>(packed) + off;
+    a.rows = d->c;
+    a.ntaps = cls[i].ntaps;
+    a.C = d->k;
+    a.Ceff = ke;
+    a.Kp = (int)tdg_round_up((long long)a.ntaps * ke, bke);
+    a.stride_tap = d->c * d->k;
+    a.stride_row = d->k;    // row = big-side channel
+    a.stride_ch = 1;        // K channel = small-side channel (contiguous in the master)
+    for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = cls[i].tap_ids[t];
+    dim3 grid(tdg_ceil_div(a.Kp, 32), tdg_ceil_div(a.rows, 32));
+    if (d->dtype == TDG_BF16)
+      hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else
+      hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    TDG_HIP_LAUNCH_CHECK("pack_filter_bwd");
+    off += (size_t)a.rows * a.Kp * es;
+  }
+  return TDG_OK;
+}
+
+static void fill_epilogue(IgArgs& a, const TdgEpilogue* epi) {
+  a.bias = epi ? epi->bias : nullptr;
+  a.act = epi ? epi->act : TDG_ACT_NONE;
+  a.leak = epi ? epi->leak : 0.f;
+  a.mask_mode = epi ? epi->mask_mode : TDG_MASK_NONE;
+  a.mask_src = epi ? epi->mask_src : nullptr;
+  if (a.mask_mode == TDG_MASK_NONE) a.mask_src = nullptr;
+}
+
+int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void* wp, void* y,
+                   const TdgEpilogue* epi, void* stream) {
+  int rc = validate_desc(d, "tdg_conv2d_fwd");
+  if (rc) return rc;
+  TDG_CHECK_ARG(n_images > 0 && n_images <= d->n, "tdg_conv2d_fwd: n_images %d outside (0, %d]", n_images, d->n);
+  TDG_CHECK_ARG(x && wp && y, "tdg_conv2d_fwd: null pointer");
+  TDG_CHECK_ARG(!epi || epi->mask_mode == TDG_MASK_NONE || epi->mask_src, "tdg_conv2d_fwd: mask without mask_src");
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  const int ce = eff_channels(d->c, d->cs, vec);
+  const bool veca = ce != 0;
+  const int C = veca ? ce : d->c;
+  IgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = x;
+  a.wpack = wp;
+  a.out = y;
+  fill_epilogue(a, epi);
+  a.src_bytes = (unsigned)((long long)n_images * d->h * d->w * d->cs * es);
+  a.w_bytes = (unsigned)tdg_packed_filter_fwd_bytes(d);
+  a.SH = d->h; a.SW = d->w; a.sigma = d->stride;
+  a.C = C; a.Cs = d->cs;
+  a.fd_c = make_fastdiv(veca ? C / vec : C);
+  a.N = d->k; a.OH = d->oh; a.OW = d->ow; a.os = 1; a.Cso = d->ks;
+  a.nclasses = 1;
+  IgClass& c = a.cls[0];
+  c.M = n_images * d->oh * d->ow;
+  c.GH = d->oh; c.GW = d->ow;
+  c.ntaps = d->kh * d->kw;
+  c.K = c.ntaps * C;
+  c.nsteps = tdg_ceil_div(c.K, bke);
+  c.Kp = c.nsteps * bke;
+  c.oh0 = c.ow0 = 0;
+  c.w_off_bytes = 0;
+  c.fd_ghw = make_fastdiv(c.GH * c.GW);
+  c.fd_gw = make_fastdiv(c.GW);
+  for (int kh = 0; kh < d->kh; ++kh)
+    for (int kw = 0; kw < d->kw; ++kw) c.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
+  const int bn = pick_bn(d->k);
+  return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
+                              : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
+}
+
+int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const void* wp, void* x,
+                        const TdgEpilogue* epi, void* stream) {
+  int rc = validate_desc(d, "tdg_conv2d_bwd_data");
+  if (rc) return rc;
+  TDG_CHECK_ARG(n_images > 0 && n_images <= d->n, "tdg_conv2d_bwd_data: n_images %d outside (0, %d]", n_images, d->n);
+  TDG_CHECK_ARG(x && wp && y, "tdg_conv2d_bwd_data: null pointer");
+  TDG_CHECK_ARG(!epi || epi->mask_mode == TDG_MASK_NONE || epi->mask_src, "tdg_conv2d_bwd_data: mask without mask_src");
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  const int ke = eff_channels(d->k, d->ks, vec);
+  const bool veca = ke != 0;
+  const int C = veca ? ke : d->k;
+  IgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = y;
+  a.wpack = wp;
+  a.out = x;
+  fill_epilogue(a, epi);
+  a.src_bytes = (unsigned)((long long)n_images * d->oh * d->ow * d->ks * es);
+  a.w_bytes = (unsigned)tdg_packed_filter_bwd_bytes(d);
+  a.SH = d->oh; a.SW = d->ow; a.sigma = 1;
+  a.C = C; a.Cs = d->ks;
+  a.fd_c = make_fastdiv(veca ? C / vec : C);
+  a.N = d->c; a.OH = d->h; a.OW = d->w; a.os = d->stride; a.Cso = d->cs;
+  BwdClassPlan plan[IG_MAX_CLASSES];
+  const int nc = plan_bwd_classes(d, plan);
+  a.nclasses = 0;
+  unsigned off = 0;
+  for (int i = 0; i < nc; ++i) {
+    const int Kp = (int)tdg_round_up((long long)plan[i].ntaps * C, bke);
+    if (plan[i].ntaps == 0 || plan[i].GH <= 0 || plan[i].GW <= 0) {
+      // a class without taps would leave its output pixels unwritten: only possible when the
+      // filter is smaller than the stride, which the reference never uses
+      TDG_CHECK_ARG(plan[i].GH <= 0 || plan[i].GW <= 0, "tdg_conv2d_bwd_data: filter smaller than stride");
+      continue;
+    }
+    IgClass& c = a.cls[a.nclasses++];
+    c.M = n_images * plan[i].GH * plan[i].GW;
+    c.GH = plan[i].GH; c.GW = plan[i].GW;
+    c.ntaps = plan[i].ntaps;
+    c.K = c.ntaps * C;
+    c.nsteps = tdg_ceil_div(c.K, bke);
+    c.Kp = Kp;
+    c.oh0 = plan[i].oh0; c.ow0 = plan[i].ow0;
+    c.w_off_bytes = off;
+    c.fd_ghw = make_fastdiv(c.GH * c.GW);
+    c.fd_gw = make_fastdiv(c.GW);
+    for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(plan[i].dh[t], plan[i].dw[t]);
+    off += (unsigned)((size_t)d->c * Kp * es);
+  }
+  const int bn = pick_bn(d->c);
+  return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
+                              : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
+}
+
+static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es;
+  const int mr = d->dtype == TDG_BF16 ? WgGeom<bf16_t>::MR : WgGeom<float>::MR;
+  int ce = eff_channels(d->c, d->cs, vec);
+  if (!ce) ce = d->c;
+  const int M = n_images * d->oh * d->ow;
+  const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, 128) * tdg_ceil_div(d->k, pick_bn(d->k));
+  int want = tdg_ceil_div(1024, tiles);                 // aim for >= ~4 workgroups per CU
+  const int max_split = tdg_ceil_div(M, mr * 4);        // keep >= 4 steps per split
+  if (want > max_split) want = max_split;
+  if (want < 1) want = 1;
+  if (want > 256) want = 256;
+  int per = (int)tdg_round_up(tdg_ceil_div(M, want), mr);
+  *m_per_split = per;
+  return tdg_ceil_div(M, per);
+}
+
+size_t tdg_conv2d_bwd_filter_workspace_bytes(const TdgConvDesc* d, int n_images) {
+  if (validate_desc(d, "tdg_conv2d_bwd_filter_workspace_bytes") != TDG_OK) return 0;
+  int per;
+  const int ns = wgrad_nsplit(d, n_images, &per);
+  return (size_t)ns * (size_t)tdg_round_up((long long)d->kh * d->kw * d->c * d->k, 4) * sizeof(float);
+}
+
+int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, const void* y, float* dw,
+                          float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = validate_desc(d, "tdg_conv2d_bwd_filter");
+  if (rc) return rc;
+  TDG_CHECK_ARG(n_images > 0 && n_images <= d->n, "tdg_conv2d_bwd_filter: n_images %d outside (0, %d]", n_images, d->n);
+  TDG_CHECK_ARG(x && y && dw && workspace, "tdg_conv2d_bwd_filter: null pointer");
+  const size_t need = tdg_conv2d_bwd_filter_workspace_bytes(d, n_images);
+  if (workspace_bytes < need) {
+    tdg_set_error("tdg_conv2d_bwd_filter: workspace %zu < %zu bytes", workspace_bytes, need);
+    return TDG_EWORKSPACE;
+  }
+  const int es = tdg_dtype_size(d->dtype), vec = 16 / es;
+  const int ce = eff_channels(d->c, d->cs, vec);
+  const bool veca = ce != 0;
+  const int C = veca ? ce : d->c;
+  // the dense operand (small side) is always read with 16-byte vectors
+  TDG_CHECK_ARG(d->ks % vec == 0, "tdg_conv2d_bwd_filter: small-side channel stride %d not a multiple of %d", d->ks, vec);
+  WgArgs a;
+  memset(&a, 0, sizeof(a));
+  a.src = x;
+  a.g = y;
+  a.slabs = static_cast<float*>(workspace);
+  a.src_bytes = (unsigned)((long long)n_images * d->h * d->w * d->cs * es);
+  a.g_bytes = (unsigned)((long long)n_images * d->oh * d->ow * d->ks * es);
+  a.M = n_images * d->oh * d->ow;
+  a.GH = d->oh; a.GW = d->ow; a.SH = d->h; a.SW = d->w; a.sigma = d->stride;
+  a.C = C; a.Clog = d->c; a.Cs = d->cs; a.ntaps = d->kh * d->kw;
+  a.KK = a.ntaps * C;
+  a.fd_c = make_fastdiv(veca ? C / vec : C);
+  a.fd_ghw = make_fastdiv(d->oh * d->ow);
+  a.fd_gw = make_fastdiv(d->ow);
+  a.N = (int)tdg_round_up(d->k, vec) <= d->ks ? (int)tdg_round_up(d->k, vec) : d->k;
+  a.Gs = d->ks;
+  a.Nlog = d->k;
+  a.nsplit = wgrad_nsplit(d, n_images, &a.m_per_split);
+  a.slab_stride = tdg_round_up((long long)a.ntaps * d->c * d->k, 4);
+  const int bn = pick_bn(d->k);
+  a.ntiles_n = tdg_ceil_div(a.N, bn);
+  a.ntiles_k = tdg_ceil_div(a.KK, 128);
+  for (int kh = 0; kh < d->kh; ++kh)
+    for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
+  rc = d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
+                            : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
+  if (rc) return rc;
+  const size_t n = (size_t)a.ntaps * d->c * d->k;
+  const int blocks = (int)(n / 4 / 256 + 1 > 2048 ? 2048 : n / 4 / 256 + 1);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.slabs, dw, n, a.nsplit,
+                     (size_t)a.slab_stride, beta);
+  TDG_HIP_LAUNCH_CHECK("slab_reduce");
+  return TDG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,182 @@
+"""Thin typed wrappers over the C ABI (include/tdg.h): torch tensors in, raw pointers out.
+
+Nothing here computes: each function marshals pointers/sizes and enqueues one library call
+on torch's current HIP stream.  `Act` describes an NHWC activation buffer with an explicit
+channel stride (padding channels are kept at zero; see DESIGN.md "Data layout in HBM").
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (F32, BF16, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID,  # noqa: F401
+                   MASK_NONE, MASK_LRELU, MASK_RELU, ConvDesc, Epilogue)
+
+TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
+ELEM_SIZE = {F32: 4, BF16: 2}
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t, byte_offset=0):
+    if t is None:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr() + byte_offset)
+
+
+def pad_channels(c, multiple=8):
+    """Channel stride of an activation buffer: multiples of 8 keep 16-byte gathers legal in
+    both dtypes; thin tensors (images, c <= 4) stay compact and take the scalar gather."""
+    return c if c <= 4 else (c + multiple - 1) // multiple * multiple
+
+
+class Act:
+    """[n, h, w, c] activation in HBM with channel stride cs (zero-filled at allocation)."""
+
+    def __init__(self, n, h, w, c, dtype, device, cs=None, buf=None):
+        self.n, self.h, self.w, self.c = n, h, w, c
+        self.cs = pad_channels(c) if cs is None else cs
+        self.dtype = dtype
+        self.buf = buf if buf is not None else torch.zeros(n * h * w * self.cs, dtype=TORCH_DTYPE[dtype], device=device)
+
+    @property
+    def rows(self):
+        return self.n * self.h * self.w
+
+    @property
+    def image_elems(self):
+        return self.h * self.w * self.cs
+
+    def ptr(self, image=0):
+        return ptr(self.buf, image * self.image_elems * ELEM_SIZE[self.dtype])
+
+    def view(self, image0, count):
+        """Sub-batch [image0, image0+count) sharing storage."""
+        e = self.image_elems
+        return Act(count, self.h, self.w, self.c, self.dtype, self.buf.device, self.cs,
+                   self.buf[image0 * e:(image0 + count) * e])
+
+    def like(self):
+        return Act(self.n, self.h, self.w, self.c, self.dtype, self.buf.device, self.cs)
+
+    # host <-> device helpers (tests / checkpoints only)
+    def set(self, array):
+        t = torch.as_tensor(array, dtype=torch.float32).reshape(self.n, self.h, self.w, self.c)
+        full = torch.zeros(self.n, self.h, self.w, self.cs, dtype=torch.float32)
+        full[..., :self.c] = t
+        self.buf.copy_(full.reshape(-1).to(self.buf.device, TORCH_DTYPE[self.dtype]))
+        return self
+
+    def get(self):
+        return self.buf.float().reshape(self.n, self.h, self.w, self.cs)[..., :self.c].cpu().numpy()
+
+
+def conv_desc(big, small, kh, kw, stride, pad_t, pad_l):
+    """Descriptor for the conv between `big` (conv input / deconv output) and `small`."""
+    assert big.dtype == small.dtype and big.n == small.n
+    return ConvDesc(big.n, big.h, big.w, big.c, big.cs, small.h, small.w, small.c, small.cs,
+                    kh, kw, stride, pad_t, pad_l, big.dtype)
+
+
+def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=None):
+    e = Epilogue()
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.act, e.leak, e.mask_mode = act, leak, mask_mode
+    e.mask_src = mask_src if isinstance(mask_src, int) or mask_src is None else mask_src.value
+    return e
+
+
+class Conv:
+    """One strided conv of the model: owns the packed filter operands and the split-K
+    workspace; exposes the three GEMM forms of include/tdg.h."""
+
+    def __init__(self, big, small, kh, kw, stride, pad_t, pad_l):
+        self.big, self.small = big, small
+        self.desc = conv_desc(big, small, kh, kw, stride, pad_t, pad_l)
+        lib = _lib.load()
+        dev = big.buf.device
+        self.fwd_bytes = lib.tdg_packed_filter_fwd_bytes(C.byref(self.desc))
+        self.bwd_bytes = lib.tdg_packed_filter_bwd_bytes(C.byref(self.desc))
+        if self.fwd_bytes == 0 or self.bwd_bytes == 0:
+            raise _lib.TdgError('conv descriptor rejected: %s' % lib.tdg_last_error().decode())
+        self.w_fwd = torch.zeros(self.fwd_bytes, dtype=torch.uint8, device=dev)
+        self.w_bwd = torch.zeros(self.bwd_bytes, dtype=torch.uint8, device=dev)
+        self.ws_bytes = lib.tdg_conv2d_bwd_filter_workspace_bytes(C.byref(self.desc), big.n)
+        self.ws = None
+        self.filter_shape = (kh, kw, big.c, small.c)
+
+    def workspace(self):
+        if self.ws is None:
+            self.ws = torch.empty(max(self.ws_bytes, 16), dtype=torch.uint8, device=self.big.buf.device)
+        return self.ws
+
+    def pack(self, w, fwd=True, bwd=True):
+        """w: f32 master filter [kh, kw, big.c, small.c] (device, contiguous)."""
+        if fwd:
+            _lib.call('tdg_pack_filter_fwd', C.byref(self.desc), ptr(w), ptr(self.w_fwd), stream())
+        if bwd:
+            _lib.call('tdg_pack_filter_bwd', C.byref(self.desc), ptr(w), ptr(self.w_bwd), stream())
+
+    def fwd(self, x_ptr, y_ptr, n_images, epi=None):
+        _lib.call('tdg_conv2d_fwd', C.byref(self.desc), n_images, x_ptr, ptr(self.w_fwd), y_ptr,
+                  C.byref(epi) if epi is not None else None, stream())
+
+    def bwd_data(self, y_ptr, x_ptr, n_images, epi=None):
+        _lib.call('tdg_conv2d_bwd_data', C.byref(self.desc), n_images, y_ptr, ptr(self.w_bwd), x_ptr,
+                  C.byref(epi) if epi is not None else None, stream())
+
+    def bwd_filter(self, x_ptr, y_ptr, dw, n_images, beta=0.0):
+        ws = self.workspace()
+        _lib.call('tdg_conv2d_bwd_filter', C.byref(self.desc), n_images, x_ptr, y_ptr, ptr(dw), beta,
+                  ptr(ws), ws.numel(), stream())
+
+
+class Workspace:
+    """Scratch for the two-stage reductions (BN, bias grads, sumsq)."""
+
+    def __init__(self, device, nbytes=8 << 20):
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def ensure(self, nbytes):
+        if self.buf.numel() < nbytes:
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.buf.device)
+        return self.buf
+
+
+def bn_fwd(ws, u, c, beta, act, pre, h, stats, rows=None, leak=0.2, eps=1e-3, u_ptr=None, pre_ptr=None, h_ptr=None):
+    rows = u.rows if rows is None else rows
+    lib = _lib.load()
+    need = lib.tdg_bn_workspace_bytes(rows, c)
+    w = ws.ensure(need)
+    _lib.call('tdg_bn_fwd', u.dtype, u_ptr or u.ptr(), rows, c, u.cs, ptr(beta), eps, act, leak,
+              pre_ptr or pre.ptr(), h_ptr or h.ptr(), ptr(stats), ptr(w), w.numel(), stream())
+
+
+def bn_bwd(ws, dh, pre, c, beta, stats, act, du, dbeta, rows=None, leak=0.2, beta_acc=0.0,
+           dh_ptr=None, pre_ptr=None, du_ptr=None):
+    rows = dh.rows if rows is None else rows
+    lib = _lib.load()
+    need = lib.tdg_bn_workspace_bytes(rows, c)
+    w = ws.ensure(need)
+    _lib.call('tdg_bn_bwd', dh.dtype, dh_ptr or dh.ptr(), pre_ptr or pre.ptr(), rows, c, dh.cs, ptr(beta), ptr(stats),
+              act, leak, du_ptr or du.ptr(), ptr(dbeta), beta_acc, ptr(w), w.numel(), stream())
+
+
+def bias_grad(ws, dy, c, db, rows=None, beta=0.0, dy_ptr=None):
+    rows = dy.rows if rows is None else rows
+    need = _lib.load().tdg_bn_workspace_bytes(rows, c)
+    w = ws.ensure(need)
+    _lib.call('tdg_bias_grad', dy.dtype, dy_ptr or dy.ptr(), rows, c, dy.cs, ptr(db), beta, ptr(w), w.numel(), stream())
+
+
+def colsum_weighted(ws, dtype, x_ptr, rows, cols, cs, coef, dw, beta=0.0):
+    need = _lib.load().tdg_colsum_workspace_bytes(rows, cols)
+    w = ws.ensure(need)
+    _lib.call('tdg_colsum_weighted', dtype, x_ptr, rows, cols, cs, ptr(coef), ptr(dw), beta, ptr(w), w.numel(), stream())
+
+
+def sumsq(ws, dtype, x_ptr, n, acc, beta=0.0):
+    w = ws.ensure(4096)
+    _lib.call('tdg_sumsq', dtype, x_ptr, n, ptr(acc), beta, ptr(w), w.numel(), stream())

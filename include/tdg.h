@@ -1,0 +1,187 @@
+/* tdg.h -- C ABI of lib3dgan_hip.so: the MI355X (gfx950) kernels behind the
+ * 3dgan training hot path (models/gan.py + ops/layers.py of algoterranean/3dgan).
+ *
+ * The reference has no native boundary: every op below is a TensorFlow-1.x op that the
+ * reference's Python graph builders instantiate, and `sess.run` executes inside the TF C++
+ * runtime.  Each entry point cites the reference call site (file:line under /root/reference)
+ * whose TF op (forward and/or the autodiff ops TF derives from it) it replaces.
+ *
+ * Conventions
+ *  - Plain C: pointers are device pointers (HBM) owned by the caller; the library allocates
+ *    nothing persistent and never synchronises.  All work is enqueued on `stream`
+ *    (a hipStream_t passed as void*).
+ *  - Every function returns 0 on success, a negative TDG_E* code otherwise, and never
+ *    throws; `tdg_last_error()` returns a thread-local message.
+ *  - Activations are NHWC with an explicit channel stride `cs` (elements) >= channels;
+ *    padding channels must hold zeros.  dtype selects the storage/compute type of
+ *    activations and packed filters: TDG_F32 (exact f32 MFMA, parity path) or TDG_BF16
+ *    (bf16 MFMA, f32 accumulate).  Master weights, gradients, optimizer state, biases,
+ *    BN parameters and all reductions are always f32.
+ */
+#ifndef TDG_H_
+#define TDG_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDG_OK 0
+#define TDG_EINVAL (-1)      /* invalid descriptor / argument            */
+#define TDG_EUNSUPPORTED (-2)/* valid but not implemented for this shape */
+#define TDG_EHIP (-3)        /* a HIP runtime call failed                */
+#define TDG_EWORKSPACE (-4)  /* workspace too small                      */
+
+#define TDG_F32 0
+#define TDG_BF16 1
+
+/* activations (fused epilogues / elementwise) */
+#define TDG_ACT_NONE 0
+#define TDG_ACT_RELU 1    /* models/gan.py:245 tf.nn.relu     */
+#define TDG_ACT_LRELU 2   /* ops/activations.py:28 max(leak*x, x) */
+#define TDG_ACT_TANH 3    /* models/gan.py:252 tf.tanh        */
+#define TDG_ACT_SIGMOID 4 /* models/gan.py:275 tf.nn.sigmoid  */
+
+/* mask applied by an epilogue: out *= act'(mask_src) evaluated from the POST-activation
+ * (lrelu) or PRE-activation (relu after BN) tensor stored at the same offsets as `out`. */
+#define TDG_MASK_NONE 0
+#define TDG_MASK_LRELU 1  /* slope 1 where mask_src > 0 else leak (TF MaximumGrad, App. A-6) */
+#define TDG_MASK_RELU 2   /* 1 where mask_src > 0 else 0 */
+
+/* One strided 2-D convolution with TF 'SAME'/'VALID' geometry between a "big" tensor
+ * x [n, h, w, c] (conv input / conv2d_transpose output) and a "small" tensor
+ * y [n, oh, ow, k] (conv output / conv2d_transpose input), filter master layout
+ * [kh, kw, c, k] f32 (HWIO for conv2d, ops/layers.py:96; [k,k,Cout,Cin] for deconv2d,
+ * ops/layers.py:135 -- same memory order with c = deconv Cout, k = deconv Cin). */
+typedef struct TdgConvDesc {
+  int32_t n, h, w, c, cs;   /* big side: dims, channels, channel stride   */
+  int32_t oh, ow, k, ks;    /* small side                                  */
+  int32_t kh, kw, stride;
+  int32_t pad_t, pad_l;     /* TF pad_before             */
+  int32_t dtype;            /* TDG_F32 | TDG_BF16                          */
+} TdgConvDesc;
+
+/* Fused epilogue of the two conv GEMM forms. */
+typedef struct TdgEpilogue {
+  const float* bias;        /* per output channel, may be NULL (tf.nn.bias_add, ops/layers.py:102,143) */
+  int32_t act;              /* TDG_ACT_*                                     */
+  float leak;               /* lrelu leak                                    */
+  int32_t mask_mode;        /* TDG_MASK_*                                    */
+  const void* mask_src;     /* tensor with the geometry of the output, dtype = desc.dtype */
+} TdgEpilogue;
+
+const char* tdg_last_error(void);
+int tdg_version(void);
+
+/* ---- filter packing: f32 master -> GEMM operand layout in desc.dtype ------------------
+ * FWD form  : rows = k (small-side channels), K = (tap, c)        -> used by tdg_conv2d_fwd
+ * BWD form  : per output-parity class, rows = c, K = (tap', k)    -> used by tdg_conv2d_bwd_data
+ * Sizes in bytes via the *_bytes queries. */
+size_t tdg_packed_filter_fwd_bytes(const TdgConvDesc* d);
+size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d);
+int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream);
+int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void* stream);
+
+/* ---- conv GEMMs -------------------------------------------------------------------------
+ * tdg_conv2d_fwd      : y = epi(conv2d(x, W))            tf.nn.conv2d, ops/layers.py:101;
+ *                       also d(conv2d_transpose)/d(input) (autodiff of ops/layers.py:142)
+ *                       and the tangent pass of the gradient penalty (models/gan.py:228)
+ * tdg_conv2d_bwd_data : x = epi(conv2d_backprop_input(W, y))   autodiff of ops/layers.py:101;
+ *                       also IS tf.nn.conv2d_transpose, ops/layers.py:142
+ * tdg_conv2d_bwd_filter: dW (+)= conv2d_backprop_filter(x, y)  autodiff of ops/layers.py:101,142
+ *                       dw = beta*dw + sum over rows; deterministic two-stage reduction.
+ * `n_images` lets a call cover a leading sub-batch of the buffers (desc.n is the capacity
+ * used for bounds only).  */
+int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void* w_packed_fwd,
+                   void* y, const TdgEpilogue* epi, void* stream);
+int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const void* w_packed_bwd,
+                        void* x, const TdgEpilogue* epi, void* stream);
+size_t tdg_conv2d_bwd_filter_workspace_bytes(const TdgConvDesc* d, int n_images);
+int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, const void* y,
+                          float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- dense fc2-style row ops (tf.matmul with one output unit, ops/layers.py:57 via
+ *      models/gan.py:285, and its autodiff) --------------------------------------------- */
+/* out[r] = act(dot(x[r, :cols], w) + bias[0]) */
+int tdg_rowdot(int dtype, const void* x, int rows, int cols, const float* w, const float* bias,
+               int act, float* out, void* stream);
+/* dx[r, c] = (dout[r] * w[c]) * mask(mask_src[r, c]) */
+int tdg_rowouter(int dtype, const float* dout, const float* w, int rows, int cols, int mask_mode,
+                 float leak, const void* mask_src, void* dx, void* stream);
+/* dw[c] = beta*dw[c] + sum_r coef[r] * x[r, c]   (coef NULL -> 1); deterministic */
+int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols, int cs, const float* coef,
+                        float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
+size_t tdg_colsum_workspace_bytes(int rows, int cols);
+
+/* ---- batch norm, training mode, no gamma (tf.contrib.layers.batch_norm defaults,
+ *      ops/layers.py:58,103,144) ------------------------------------------
+ * fwd : pre = (u - mean) * rsqrt(var + eps) + beta ; h = act(pre)   (u over `rows` x c)
+ *       stats[0:c] = mean, stats[c:2c] = rstd (saved for backward)
+ * bwd : dpre = dh * act'(pre); du = rstd * (dpre - mean(dpre) - xhat * mean(dpre*xhat));
+ *       dbeta = beta_acc*dbeta + sum(dpre)                                                */
+size_t tdg_bn_workspace_bytes(int rows, int c);
+int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps,
+               int act, float leak, void* pre, void* h, float* stats, void* workspace,
+               size_t workspace_bytes, void* stream);
+int tdg_bn_bwd(int dtype, const void* dh, const void* pre, int rows, int c, int cs,
+               const float* beta, const float* stats, int act, float leak, void* du, float* dbeta,
+               float beta_acc, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- elementwise ------------------------------------------------------------------------ */
+/* y = act(x + bias[c]) over rows x c (tf.nn.bias_add + activation) */
+int tdg_bias_act(int dtype, const void* x, int rows, int c, int cs, const float* bias, int act,
+                 float leak, void* y, void* stream);
+/* dx = dy * act'(.) given the post-activation tensor (tanh/sigmoid/lrelu) */
+int tdg_act_bwd(int dtype, const void* dy, const void* post, size_t n, int act, float leak, void* dx,
+                void* stream);
+/* out = scale * (in + shift), f32 in -> dtype out   (models/gan.py:50: 2*(x-0.5)) */
+int tdg_affine_cast(int dtype, const float* in, size_t n, float scale, float shift, void* out, void* stream);
+int tdg_cast_to_f32(int dtype, const void* in, size_t n, float* out, void* stream);
+int tdg_cast_from_f32(int dtype, const float* in, size_t n, void* out, void* stream);
+/* xhat[r,:] = x[r,:] + alpha[r] * (g[r,:] - x[r,:])   (models/gan.py:225-226) */
+int tdg_gp_interp(int dtype, const void* x, const void* g, const float* alpha, int rows, int cols,
+                  void* xhat, void* stream);
+/* acc[0] = beta*acc[0] + sum(x^2) over n elements (models/gan.py:229); deterministic */
+int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* workspace,
+              size_t workspace_bytes, void* stream);
+size_t tdg_reduce_workspace_bytes(size_t n);
+/* out[0] = mean(x[0:n]) f32 input (tf.reduce_mean of D outputs, models/gan.py:196-204) */
+int tdg_mean_f32(const float* x, int n, float* out, void* stream);
+/* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
+ * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
+int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);
+/* out = coef[0] * in   (u = d penalty / d v, coefficient read from device memory) */
+int tdg_scale_by_dev(int dtype, const void* in, size_t n, const float* coef, void* out, void* stream);
+/* x[i] = value for i < n (f32) */
+int tdg_fill_f32(float* x, size_t n, float value, void* stream);
+/* column sums of a rows x c activation: db[c] = beta*db[c] + sum_r dy[r,c] (bias gradient) */
+int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs, float* db, float beta,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- optimizers on flat f32 buckets (tf.train.*Optimizer via util.py:150-183) ----------- */
+/* Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller */
+int tdg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
+                  float beta2, float eps, float grad_scale, void* stream);
+/* RMSProp (rms slot initialised to 1 by the caller), optional momentum, not centered */
+int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom, size_t n, float lr,
+                     float decay, float momentum, float eps, float grad_scale, void* stream);
+int tdg_sgd_momentum_step(float* p, const float* g, float* acc, size_t n, float lr, float momentum,
+                          float grad_scale, void* stream);
+/* p = clamp(p, lo, hi)  (models/gan.py:142-143; never executed by the reference, App. C-3) */
+int tdg_clamp(float* p, size_t n, float lo, float hi, void* stream);
+/* flag[0] = 1 if any element is NaN/Inf (hem/util/training.py:52-53 tf.check_numerics) */
+int tdg_check_finite(const float* x, size_t n, int* flag, void* stream);
+
+/* ---- RNG: Philox4x32-10 counter streams (tf.random_normal / tf.random_uniform,
+ *      models/gan.py:246,224) -------------------------------------------------------------- */
+int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n,
+                      void* out, void* stream);
+int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDG_H_ */

@@ -1,0 +1,242 @@
+"""GPU parity of the individual HIP kernels (through the C ABI) against the NumPy oracle.
+
+Tolerances: f32 path 2e-5 relative to the output's max magnitude (exact-f32 MFMA, only the
+summation order differs from NumPy); bf16 path 2e-2 (inputs rounded to bf16, f32 accumulate).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 2e-5, 1: 2e-2}
+
+
+def relerr(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def bf16_round(a):
+    return torch.tensor(a, dtype=torch.float32).bfloat16().float().numpy()
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride
+    (2, 32, 32, 3, 16, 5, 2),      # thin input: scalar gather (c1)
+    (3, 16, 16, 8, 24, 5, 2),      # vector gather, ragged N
+    (2, 8, 8, 40, 104, 5, 2),
+    (2, 8, 8, 200, 400, 5, 2),     # c2-like channels, BN=208 tile
+    (4, 4, 4, 16, 8, 1, 1),        # 1x1 (VAE c5/c6)
+    (2, 16, 16, 4, 64, 4, 2),      # pix2pix k4 s2
+    (5, 1, 1, 24, 136, 1, 1),      # dense as 1x1 conv on 1x1 images (fc1)
+    (2, 7, 9, 12, 20, 5, 2),       # odd spatial sizes
+    (2, 16, 16, 3, 100, 5, 2),     # dc4 geometry: big side c=3 (scalar), small side 100 -> stride 104
+]
+
+
+def make_conv(K, dtype, n, h, w, cin, cout, k, s, dev):
+    oh, pt, _ = T.same_pad(h, k, s)
+    ow, pl, _ = T.same_pad(w, k, s)
+    big = K.Act(n, h, w, cin, dtype, dev)
+    small = K.Act(n, oh, ow, cout, dtype, dev)
+    conv = K.Conv(big, small, k, k, s, pt, pl)
+    return big, small, conv
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_bwd(case, dtype):
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(hash(case) % 1000)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev)
+    dy = rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32)
+    if dtype == 1:
+        x, Wt, dy = bf16_round(x), bf16_round(Wt), bf16_round(dy)
+    wd = torch.tensor(Wt, device=dev)
+    bd = torch.tensor(b, device=dev)
+    conv.pack(wd)
+    # ---- forward with bias + lrelu
+    big.set(x)
+    conv.fwd(big.ptr(), small.ptr(), n, K.epilogue(bias=bd, act=K.ACT_LRELU, leak=0.2))
+    ref = T.lrelu(T.conv2d(x.astype(np.float64), Wt.astype(np.float64), s) + b)
+    assert relerr(small.get(), ref) < TOL[dtype]
+    # padding channels must stay zero
+    full = small.buf.float().reshape(n, small.h, small.w, small.cs).cpu().numpy()
+    assert np.all(full[..., cout:] == 0)
+    # ---- backward data with lrelu mask taken from x
+    small.set(dy)
+    mask_src = big.like().set(x)
+    out = big.like()
+    conv.bwd_data(small.ptr(), out.ptr(), n, K.epilogue(mask_mode=K.MASK_LRELU, mask_src=mask_src.ptr(), leak=0.2))
+    ref = T.conv2d_backprop_input(x.shape, Wt.astype(np.float64), dy.astype(np.float64), s) * T.lrelu_grad_mask(x.astype(np.float64))
+    assert relerr(out.get(), ref) < TOL[dtype]
+    # ---- backward filter (accumulating: beta = 1 on a pre-filled gradient)
+    dw = torch.full((k, k, cin, cout), 0.5, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n, beta=1.0)
+    ref = T.conv2d_backprop_filter(x.astype(np.float64), Wt.shape, dy.astype(np.float64), s) + 0.5
+    assert relerr(dw.cpu().numpy(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_conv_subbatch_and_classes(dtype):
+    """n_images < capacity with a pointer offset (the slot scheme of the D passes)."""
+    K = pkg('kernels')
+    dev = torch.device('cuda:0')
+    n, h, w, cin, cout, k, s = 6, 8, 8, 16, 32, 5, 2
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / 20).astype(np.float32)
+    if dtype == 1:
+        x, Wt = bf16_round(x), bf16_round(Wt)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev)
+    conv.pack(torch.tensor(Wt, device=dev))
+    big.set(x)
+    conv.fwd(big.ptr(2), small.ptr(2), 3)
+    got = small.get()
+    ref = T.conv2d(x[2:5].astype(np.float64), Wt.astype(np.float64), s)
+    assert relerr(got[2:5], ref) < TOL[dtype]
+    assert np.all(got[:2] == 0) and np.all(got[5:] == 0)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('shape', [(512, 200), (96, 3), (1000, 1), (64, 800)])
+def test_batch_norm(shape, dtype):
+    K = pkg('kernels')
+    dev = torch.device('cuda:0')
+    rows, c = shape
+    rng = np.random.default_rng(3)
+    u = (rng.standard_normal((rows, c)) * 2 + 0.7).astype(np.float32)
+    beta = rng.standard_normal(c).astype(np.float32)
+    dh = rng.standard_normal((rows, c)).astype(np.float32)
+    if dtype == 1:
+        u, dh = bf16_round(u), bf16_round(dh)
+    ws = K.Workspace(dev)
+    ua = K.Act(rows, 1, 1, c, dtype, dev).set(u)
+    pre, hh, du = ua.like(), ua.like(), ua.like()
+    stats = torch.zeros(2 * c, device=dev)
+    bd = torch.tensor(beta, device=dev)
+    K.bn_fwd(ws, ua, c, bd, K.ACT_RELU, pre, hh, stats)
+    ref_pre, cache = T.batch_norm_train(u.astype(np.float64), beta.astype(np.float64))
+    assert relerr(pre.get().reshape(rows, c), ref_pre) < TOL[dtype]
+    assert relerr(hh.get().reshape(rows, c), T.relu(ref_pre)) < TOL[dtype]
+    dha = K.Act(rows, 1, 1, c, dtype, dev).set(dh)
+    dbeta = torch.zeros(c, device=dev)
+    # backward consumes the device's own `pre` (what the product path does)
+    K.bn_bwd(ws, dha, pre, c, bd, stats, K.ACT_RELU, du, dbeta)
+    pre_dev = pre.get().reshape(rows, c).astype(np.float64)
+    dpre = dh * (pre_dev > 0)
+    xhat = pre_dev - beta
+    rstd = cache[1]
+    ref_du = rstd * (dpre - dpre.mean(0) - xhat * (dpre * xhat).mean(0))
+    assert relerr(du.get().reshape(rows, c), ref_du) < 5 * TOL[dtype]
+    assert relerr(dbeta.cpu().numpy(), dpre.sum(0)) < 5 * TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_row_ops_and_reductions(dtype):
+    K = pkg('kernels')
+    L = pkg('_lib')
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    rows, cols = 48, 1280
+    x = rng.standard_normal((rows, cols)).astype(np.float32)
+    if dtype == 1:
+        x = bf16_round(x)
+    w = rng.standard_normal(cols).astype(np.float32)
+    b = np.array([0.3], np.float32)
+    xd = torch.tensor(x, device=dev).to(K.TORCH_DTYPE[dtype])
+    wd, bd = torch.tensor(w, device=dev), torch.tensor(b, device=dev)
+    out = torch.zeros(rows, device=dev)
+    L.call('tdg_rowdot', dtype, K.ptr(xd), rows, cols, K.ptr(wd), K.ptr(bd), K.ACT_NONE, K.ptr(out), K.stream())
+    assert relerr(out.cpu().numpy(), x.astype(np.float64) @ w + 0.3) < TOL[dtype]
+    # rowouter with lrelu mask
+    dout = torch.tensor(rng.standard_normal(rows).astype(np.float32), device=dev)
+    dx = torch.zeros(rows, cols, device=dev, dtype=K.TORCH_DTYPE[dtype])
+    L.call('tdg_rowouter', dtype, K.ptr(dout), K.ptr(wd), rows, cols, K.MASK_LRELU, 0.2, K.ptr(xd), K.ptr(dx), K.stream())
+    ref = np.outer(dout.cpu().numpy(), w) * np.where(x > 0, 1.0, 0.2)
+    assert relerr(dx.float().cpu().numpy(), ref) < TOL[dtype]
+    # weighted column sum
+    ws = K.Workspace(dev)
+    dw = torch.ones(cols, device=dev)
+    K.colsum_weighted(ws, dtype, K.ptr(xd), rows, cols, cols, dout, dw, beta=1.0)
+    assert relerr(dw.cpu().numpy(), 1.0 + dout.cpu().numpy().astype(np.float64) @ x) < TOL[dtype]
+    # sumsq + gp scalars
+    acc = torch.zeros(1, device=dev)
+    K.sumsq(ws, dtype, K.ptr(xd), rows * cols, acc)
+    ss = float((x.astype(np.float64) ** 2).sum())
+    assert abs(acc.item() - ss) / ss < 1e-5
+    scal = torch.zeros(2, device=dev)
+    L.call('tdg_gp_scalars', K.ptr(acc), 10.0, K.ptr(scal), K.stream())
+    s = np.sqrt(ss)
+    assert np.allclose(scal.cpu().numpy(), [(s - 1) ** 2, 20 * (s - 1) / s], rtol=1e-5)
+    # interpolation
+    g = rng.standard_normal((rows, cols)).astype(np.float32)
+    al = rng.uniform(0, 1, rows).astype(np.float32)
+    gd = torch.tensor(g, device=dev).to(K.TORCH_DTYPE[dtype])
+    ad = torch.tensor(al, device=dev)
+    xh = torch.zeros_like(xd)
+    L.call('tdg_gp_interp', dtype, K.ptr(xd), K.ptr(gd), K.ptr(ad), rows, cols, K.ptr(xh), K.stream())
+    gq = gd.float().cpu().numpy()
+    assert relerr(xh.float().cpu().numpy(), x + al[:, None] * (gq - x)) < TOL[dtype]
+    # bias grad on a thin tensor
+    ya = K.Act(rows, 4, 4, 3, dtype, dev)
+    yv = rng.standard_normal((rows, 4, 4, 3)).astype(np.float32)
+    if dtype == 1:
+        yv = bf16_round(yv)
+    ya.set(yv)
+    db = torch.zeros(3, device=dev)
+    K.bias_grad(ws, ya, 3, db)
+    assert relerr(db.cpu().numpy(), yv.astype(np.float64).reshape(-1, 3).sum(0)) < TOL[dtype]
+
+
+def test_optimizers_match_tf_rules():
+    K = pkg('kernels')
+    L = pkg('_lib')
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    n = 1000
+    p0 = rng.standard_normal(n).astype(np.float32)
+    grads = [rng.standard_normal(n).astype(np.float32) for _ in range(3)]
+    # Adam
+    ref = {'p': p0.copy().astype(np.float64)}
+    opt = T.Adam(1e-2, 0.5, 0.9)
+    p = torch.tensor(p0, device=dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    for t, g in enumerate(grads, start=1):
+        opt.apply(ref, {'p': g.astype(np.float64)})
+        lr_t = 1e-2 * np.sqrt(1 - 0.9 ** t) / (1 - 0.5 ** t)
+        L.call('tdg_adam_step', K.ptr(p), K.ptr(torch.tensor(g, device=dev)), K.ptr(m), K.ptr(v), n, lr_t, 0.5, 0.9, 1e-8, 1.0, K.stream())
+    assert relerr(p.cpu().numpy(), ref['p']) < 1e-5
+    # RMSProp with the reference's defaults (momentum 0.01, rms slot starts at 1)
+    ref = {'p': p0.copy().astype(np.float64)}
+    opt = T.RMSProp(1e-3, 0.9, 0.01)
+    p = torch.tensor(p0, device=dev); rms = torch.ones(n, device=dev); mom = torch.zeros(n, device=dev)
+    for g in grads:
+        opt.apply(ref, {'p': g.astype(np.float64)})
+        L.call('tdg_rmsprop_step', K.ptr(p), K.ptr(torch.tensor(g, device=dev)), K.ptr(rms), K.ptr(mom), n, 1e-3, 0.9, 0.01, 1e-10, 1.0, K.stream())
+    assert relerr(p.cpu().numpy(), ref['p']) < 1e-5
+
+
+def test_rng_statistics():
+    K = pkg('kernels')
+    L = pkg('_lib')
+    dev = torch.device('cuda:0')
+    n = 1 << 20
+    z = torch.zeros(n, device=dev)
+    L.call('tdg_random_normal', 0, 1234, 1, 0, n, K.ptr(z), K.stream())
+    assert abs(z.mean().item()) < 5e-3 and abs(z.std().item() - 1) < 5e-3
+    u = torch.zeros(n, device=dev)
+    L.call('tdg_random_uniform_f32', 1234, 2, 0, n, K.ptr(u), K.stream())
+    assert 0 <= u.min().item() and u.max().item() < 1 and abs(u.mean().item() - 0.5) < 2e-3
+    z2 = torch.zeros(n, device=dev)
+    L.call('tdg_random_normal', 0, 1234, 1, 0, n, K.ptr(z2), K.stream())
+    assert torch.equal(z, z2)            # counter-based: same key/counter -> same stream
