@@ -1,0 +1,388 @@
+"""Execution engine: binds the `Net`s recorded by ops/layers.py to HBM buffers and runs their
+forward / backward / tangent passes as sequences of HIP kernels (include/tdg.h).
+
+This replaces what TensorFlow does for the reference between graph construction and
+`sess.run` (SURVEY.md L0 + the graph half of L1/L2): variable storage (`ParamStore`, one flat
+f32 bucket per net so one RCCL all-reduce and one fused optimizer launch cover a whole net),
+autodiff (hand-scheduled, including the second-order term of the gradient penalty), and the
+optimizers of `util.py:150-183`.
+
+Data layout in HBM: activations NHWC in the compute dtype with a channel stride
+rounded up to 8 (zero padded); master weights, gradients and optimizer slots f32 in flat
+buckets; each conv keeps two packed copies of its filter (forward / backward-data GEMM
+operand layouts) that are refreshed after every optimizer step.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import kernels as K
+from .ops import activations as A
+
+
+# ------------------------------------------------------------------------------ parameters
+class ParamStore:
+    """Flat f32 parameter / gradient buckets of one net with named views
+    (names as in the reference: `generator/vars/fc1/weights`, `generator/BatchNorm/beta`)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.index = {}            # name -> (offset, shape)
+        self.size = 0
+        self.params = self.grads = None
+        self.views, self.grad_views = {}, {}
+
+    def declare(self, name, shape):
+        if name in self.index:
+            raise ValueError('variable %s already exists' % name)
+        n = int(np.prod(shape))
+        self.index[name] = (self.size, tuple(shape))
+        self.size += (n + 3) // 4 * 4                    # keep every variable 16-byte aligned
+
+    def allocate(self):
+        self.params = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(self.size, dtype=torch.float32, device=self.device)
+        for name, (off, shape) in self.index.items():
+            n = int(np.prod(shape))
+            self.views[name] = self.params[off:off + n].view(shape)
+            self.grad_views[name] = self.grads[off:off + n].view(shape)
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def grad(self, name):
+        return self.grad_views[name]
+
+    def load(self, arrays):
+        for name in self.index:
+            self.views[name].copy_(torch.as_tensor(np.asarray(arrays[name]), dtype=torch.float32))
+
+    def state_dict(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.views.items()}
+
+    def grads_dict(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.grad_views.items()}
+
+    def num_params(self):
+        return sum(int(np.prod(s)) for _, s in self.index.values())
+
+
+def xavier_uniform_(t, shape, gen):
+    """tf.contrib.layers.xavier_initializer(), also used for biases (ops/layers.py:52-53; App. A-4)."""
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    else:
+        rf = int(np.prod(shape[:-2])) if len(shape) > 2 else 1
+        fan_in, fan_out = rf * shape[-2], rf * shape[-1]
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    t.copy_((torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * lim)
+
+
+# ------------------------------------------------------------------------------ optimizers
+class Optimizer:
+    """TF-1.x update rules on a flat bucket; `grad_scale` folds the
+    1/n_replicas of `average_gradients` (util.py:138-139) into the fused step."""
+
+    def __init__(self, store):
+        self.store = store
+        self.t = 0
+
+    def _slot(self, fill=0.0):
+        return torch.full_like(self.store.params, fill)
+
+    def state_tensors(self):
+        return {}
+
+
+class Adam(Optimizer):
+    def __init__(self, store, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+        super().__init__(store)
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m, self.v = self._slot(), self._slot()
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        s = self.store
+        _lib.call('tdg_adam_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.m), K.ptr(self.v), s.size,
+                  lr_t, self.b1, self.b2, self.eps, grad_scale, K.stream())
+
+    def state_tensors(self):
+        return {'m': self.m, 'v': self.v}
+
+
+class RMSProp(Optimizer):
+    def __init__(self, store, lr, decay=0.9, momentum=0.0, eps=1e-10, centered=False):
+        super().__init__(store)
+        if centered:
+            raise NotImplementedError('--centered RMSProp is out of scope (SURVEY.md K14)')
+        self.lr, self.decay, self.mu, self.eps = lr, decay, momentum, eps
+        self.rms, self.mom = self._slot(1.0), self._slot()        # rms slot starts at ONE in TF
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        s = self.store
+        _lib.call('tdg_rmsprop_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.rms), K.ptr(self.mom), s.size,
+                  self.lr, self.decay, self.mu, self.eps, grad_scale, K.stream())
+
+    def state_tensors(self):
+        return {'rms': self.rms, 'mom': self.mom}
+
+
+class Momentum(Optimizer):
+    def __init__(self, store, lr, momentum=0.0):
+        super().__init__(store)
+        self.lr, self.mu = lr, momentum
+        self.acc = self._slot()
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        s = self.store
+        _lib.call('tdg_sgd_momentum_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.acc), s.size,
+                  self.lr, self.mu, grad_scale, K.stream())
+
+    def state_tensors(self):
+        return {'acc': self.acc}
+
+
+# ------------------------------------------------------------------------------ sequential net
+def _alias(act, h, w, c):
+    """Same storage, different logical NHWC shape (tf.reshape); needs an unpadded layout."""
+    if (act.h, act.w, act.c) == (h, w, c):
+        return act
+    if act.cs != act.c or act.h * act.w * act.c != h * w * c or K.pad_channels(c) != c:
+        raise ValueError('reshape between layers needs unpadded channel layouts (%s -> %s)' %
+                         ((act.h, act.w, act.c, act.cs), (h, w, c)))
+    return K.Act(act.n, h, w, c, act.dtype, act.buf.device, c, act.buf)
+
+
+class BoundLayer:
+    pass
+
+
+class SeqNet:
+    """A chain of dense/conv2d/deconv2d layers bound to buffers for `capacity` images.
+
+    Gradient bookkeeping per layer i:  delta[i] = dL/d(conv output incl. bias);
+    gout[i] = dL/d(layer output after BN/activation) when that is a separate tensor
+    (layers with BN, tanh or sigmoid); otherwise the consumer's backward-data epilogue
+    multiplies by the (l)relu derivative and writes delta[i] directly.
+    """
+
+    def __init__(self, net, capacity, in_shape, dtype, device, store, n_bn_passes=1, need_input_grad=False,
+                 tangent_capacity=0, ws=None, out_act=None, out_grad=None):
+        self.net, self.cap, self.dtype, self.device, self.store = net, capacity, dtype, device, store
+        self.ws = ws or K.Workspace(device)
+        self.n_bn_passes = n_bn_passes
+        h, w, c = in_shape
+        self.x = K.Act(capacity, h, w, c, dtype, device)                   # net input
+        self.dx = K.Act(capacity, h, w, c, dtype, device) if need_input_grad else None
+        self.layers = []
+        prev = self.x
+        prev_g = self.dx
+        cum = 1
+        for idx, spec in enumerate(net.layers):
+            L = BoundLayer()
+            L.spec, L.idx = spec, idx
+            ih, iw, ic = spec.in_shape
+            oh, ow, oc = spec.out_shape
+            # one dense "image row" may be a fraction of an image
+            local = (prev.h * prev.w * prev.c) // (ih * iw * ic)
+            cum *= local
+            rpi = L.rpi = cum                        # rows of this layer per original image
+            L.inp = _alias_rows(prev, local, ih, iw, ic)
+            L.gin = _alias_rows(prev_g, local, ih, iw, ic) if prev_g is not None else None
+            L.act = spec.act if spec.act is not None else A.identity
+            L.rowdot = spec.kind == 'dense' and spec.out_size == 1
+            L.wname, L.bname = net.var_name(spec, 'weights'), net.var_name(spec, 'bias')
+            if L.rowdot:
+                L.out = torch.zeros(capacity * rpi, dtype=torch.float32, device=device)       # f32 scores
+                L.seed = torch.zeros(capacity * rpi, dtype=torch.float32, device=device)      # dL/d(score)
+                L.h = L.pre = L.delta = L.gout = None
+            else:
+                last = idx == len(net.layers) - 1
+                L.h = out_act if (last and out_act is not None) else K.Act(capacity * rpi, oh, ow, oc, dtype, device)
+                if (L.h.n, L.h.h, L.h.w, L.h.c) != (capacity * rpi, oh, ow, oc):
+                    raise ValueError('out_act does not match the last layer output')
+                L.pre = L.h.like() if spec.use_bn else None
+                L.delta = L.h.like()
+                sep = spec.use_bn or L.act.code in (K.ACT_TANH, K.ACT_SIGMOID)
+                L.gout = L.h.like() if sep else L.delta
+                if last and out_grad is not None:
+                    if not sep:
+                        L.delta = out_grad
+                    L.gout = out_grad
+                if spec.use_bn:
+                    L.bn_stats = [torch.zeros(2 * oc, dtype=torch.float32, device=device) for _ in range(n_bn_passes)]
+                    L.bn_names = [net.bn_name(p, idx) for p in range(n_bn_passes)]
+                if spec.kind == 'deconv2d':
+                    big, small = L.h, L.inp
+                else:
+                    big, small = L.inp, L.h
+                if spec.padding == 'SAME':
+                    pt = max((small.h - 1) * spec.stride + spec.k - big.h, 0) // 2
+                    pl = max((small.w - 1) * spec.stride + spec.k - big.w, 0) // 2
+                else:
+                    pt = pl = 0
+                L.conv = K.Conv(big, small, spec.k, spec.k, spec.stride, pt, pl)
+                L.tan = K.Act(tangent_capacity * rpi, oh, ow, oc, dtype, device) if tangent_capacity else None
+            self.layers.append(L)
+            prev, prev_g = (L.h, L.gout) if not L.rowdot else (None, None)
+        self.tangent_capacity = tangent_capacity
+        if tangent_capacity:
+            self.tan_in = K.Act(tangent_capacity, h, w, c, dtype, device)
+
+    # -- variables ---------------------------------------------------------------------------------
+    def declare_variables(self):
+        for L in self.layers:
+            self.store.declare(L.wname, L.spec.filter_shape)
+            self.store.declare(L.bname, (L.spec.out_size,))
+        for p in range(self.n_bn_passes):
+            for L in self.layers:
+                if L.spec.use_bn:
+                    self.store.declare(L.bn_names[p], (L.spec.out_size,))
+
+    def init_variables(self, gen):
+        """Fresh variables: xavier-uniform weights and biases, zero betas (App. A-3/A-4);
+        'normal0.02' (pix2pix, hem/models/pix2pix.py:180) draws N(0, 0.02)."""
+        for L in self.layers:
+            for name, shape in ((L.wname, L.spec.filter_shape), (L.bname, (L.spec.out_size,))):
+                cpu = torch.empty(shape, dtype=torch.float32)
+                if L.spec.init == 'xavier':
+                    xavier_uniform_(cpu, shape, gen)
+                else:
+                    cpu.copy_(torch.randn(shape, generator=gen) * 0.02)
+                self.store[name].copy_(cpu)
+
+    def repack(self):
+        """Refresh the packed GEMM operands from the f32 masters (after every optimizer step)."""
+        for L in self.layers:
+            if not L.rowdot:
+                L.conv.pack(self.store[L.wname])
+
+    # -- forward -----------------------------------------------------------------------------------
+    def forward(self, img0, n, bn_pass=0):
+        """Layers on images [img0, img0+n).  Returns the last layer's output (Act or f32 scores)."""
+        for L in self.layers:
+            r0, rn = img0 * L.rpi, n * L.rpi
+            if L.rowdot:
+                cols = L.spec.in_size
+                _lib.call('tdg_rowdot', self.dtype, L.inp.ptr(r0), rn, cols, K.ptr(self.store[L.wname]),
+                          K.ptr(self.store[L.bname]), L.act.code, K.ptr(L.out, 4 * r0), K.stream())
+                continue
+            bias = self.store[L.bname]
+            if L.spec.use_bn:
+                epi = K.epilogue(bias=bias)
+                target = L.pre
+            else:
+                epi = K.epilogue(bias=bias, act=L.act.code, leak=L.act.leak)
+                target = L.h
+            if L.spec.kind == 'deconv2d':
+                L.conv.bwd_data(L.inp.ptr(r0), target.ptr(r0), rn, epi)
+            else:
+                L.conv.fwd(L.inp.ptr(r0), target.ptr(r0), rn, epi)
+            if L.spec.use_bn:
+                rows = rn * L.h.h * L.h.w
+                K.bn_fwd(self.ws, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
+                         L.bn_stats[bn_pass], rows=rows, leak=L.act.leak,
+                         u_ptr=L.pre.ptr(r0), pre_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
+        last = self.layers[-1]
+        return last.out if last.rowdot else last.h
+
+    # -- backward ----------------------------------------------------------------------------------
+    def backward(self, img0, n, bn_pass=0, want_params=True, want_dx=False, acc=False, param_images=None,
+                 dx_images=None):
+        """Backprop from the last layer's seed (rowdot: L.seed; else L.gout) on images
+        [img0, img0+n).  Parameter gradients cover `param_images` = (first, count) (default: the same
+        range) and are accumulated into the store when `acc`.  Returns dL/d(net input) if asked."""
+        beta = 1.0 if acc else 0.0
+        p0, pn = (img0, n) if param_images is None else param_images
+        g = self.store.grad
+        for L in reversed(self.layers):
+            r0, rn = img0 * L.rpi, n * L.rpi
+            q0, qn = p0 * L.rpi, pn * L.rpi
+            below = self.layers[L.idx - 1] if L.idx > 0 else None
+            need_in = below is not None or want_dx
+            d0, dn, dimg = r0, rn, img0
+            if below is None and want_dx and dx_images is not None:      # restrict the input gradient
+                d0, dn, dimg = dx_images[0] * L.rpi, dx_images[1] * L.rpi, dx_images[0]
+            if below is not None and not below.spec.use_bn and below.act.code in (K.ACT_LRELU, K.ACT_RELU):
+                mmode = K.MASK_LRELU if below.act.code == K.ACT_LRELU else K.MASK_RELU
+                msrc, mleak = below.h, below.act.leak
+            else:
+                mmode, msrc, mleak = K.MASK_NONE, None, 0.0
+            if L.rowdot:
+                cols = L.spec.in_size
+                if want_params and qn > 0:
+                    K.colsum_weighted(self.ws, self.dtype, L.inp.ptr(q0), qn, cols, cols, _sub(L.seed, q0, qn),
+                                      g(L.wname), beta)
+                    K.colsum_weighted(self.ws, K.F32, K.ptr(L.seed, 4 * q0), qn, 1, 1, None, g(L.bname), beta)
+                if need_in:
+                    _lib.call('tdg_rowouter', self.dtype, K.ptr(L.seed, 4 * d0), K.ptr(self.store[L.wname]), dn, cols,
+                              mmode, mleak, msrc.ptr(dimg * below.rpi) if msrc is not None else None, L.gin.ptr(d0), K.stream())
+                continue
+            # dL/d(conv output)
+            hw = L.h.h * L.h.w
+            if L.spec.use_bn:
+                K.bn_bwd(self.ws, L.gout, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.bn_stats[bn_pass],
+                         L.act.code, L.delta, g(L.bn_names[bn_pass]), rows=rn * hw, leak=L.act.leak, beta_acc=0.0,
+                         dh_ptr=L.gout.ptr(r0), pre_ptr=L.pre.ptr(r0), du_ptr=L.delta.ptr(r0))
+            elif L.act.code in (K.ACT_TANH, K.ACT_SIGMOID):
+                _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,
+                          L.act.leak, L.delta.ptr(r0), K.stream())
+            elif L.idx == len(self.layers) - 1 and L.act.code in (K.ACT_LRELU, K.ACT_RELU):
+                _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,
+                          L.act.leak, L.delta.ptr(r0), K.stream())
+            if want_params and qn > 0:
+                K.bias_grad(self.ws, L.delta, L.spec.out_size, g(L.bname), rows=qn * hw, beta=beta, dy_ptr=L.delta.ptr(q0))
+                if L.spec.kind == 'deconv2d':
+                    L.conv.bwd_filter(L.delta.ptr(q0), L.inp.ptr(q0), g(L.wname), qn, beta)
+                else:
+                    L.conv.bwd_filter(L.inp.ptr(q0), L.delta.ptr(q0), g(L.wname), qn, beta)
+            if need_in:
+                epi = K.epilogue(mask_mode=mmode, leak=mleak, mask_src=msrc.ptr(dimg * below.rpi) if msrc is not None else None)
+                if L.spec.kind == 'deconv2d':
+                    L.conv.fwd(L.delta.ptr(d0), L.gin.ptr(d0), dn, epi)
+                else:
+                    L.conv.bwd_data(L.delta.ptr(d0), L.gin.ptr(d0), dn, epi)
+        return self.dx
+
+    # -- gradient-penalty tangent pass (models/gan.py:228 second order; oracle/gan_ref.py) -------
+    def tangent_backward(self, img0, n, acc=True):
+        """With u in `self.tan_in` (n images) and the first-order deltas of images [img0, img0+n)
+        in place: t_i = act'(h_i) * conv_i(t_{i-1}) (no bias), dW_i += bwd_filter(t_{i-1}, delta_i),
+        d(fc2 weights) += sum_rows t_last.  Only BN-free (l)relu critics (the iwgan D)."""
+        beta = 1.0 if acc else 0.0
+        g = self.store.grad
+        t_prev = self.tan_in
+        for L in self.layers:
+            r0, rn = img0 * L.rpi, n * L.rpi
+            if L.rowdot:
+                cols = L.spec.in_size
+                K.colsum_weighted(self.ws, self.dtype, t_prev.ptr(0), rn, cols, cols, None, g(L.wname), beta)
+                break
+            if L.spec.use_bn or L.spec.kind == 'deconv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
+                raise NotImplementedError('tangent pass: layer %s is not a BN-free (l)relu conv' % L.spec.name)
+            t_in = _alias_rows(t_prev, L.rpi, *L.spec.in_shape) if t_prev is not self.tan_in else self.tan_in
+            L.conv.bwd_filter(t_in.ptr(0), L.delta.ptr(r0), g(L.wname), rn, beta)
+            mmode = K.MASK_LRELU if L.act.code == K.ACT_LRELU else K.MASK_RELU
+            L.conv.fwd(t_in.ptr(0), L.tan.ptr(0), rn, K.epilogue(mask_mode=mmode, leak=L.act.leak, mask_src=L.h.ptr(r0)))
+            t_prev = L.tan
+
+
+def _alias_rows(act, rpi, h, w, c):
+    """View `act` ([n, ...]) as [n*rpi, h, w, c]."""
+    if act is None:
+        return None
+    if rpi == 1:
+        return _alias(act, h, w, c)
+    if act.cs != act.c or K.pad_channels(c) != c:
+        raise ValueError('row-splitting reshape needs unpadded layouts')
+    return K.Act(act.n * rpi, h, w, c, act.dtype, act.buf.device, c, act.buf)
+
+
+def _sub(t, start, count):
+    return t[start:start + count]

@@ -1,0 +1,272 @@
+"""GAN / WGAN / IWGAN on MI355X -- the builder surface of the reference's `models/gan.py`
+(gan :39-91, losses :178-211, gradient_penalty :214-231, generator :234-254,
+discriminator :257-287, step policies :110-175) with the TensorFlow tower code replaced by
+a hand-scheduled sequence of HIP kernels per replica.
+
+What is kept: `gan(x, args)` returns `train_func(sess, args) -> {'g_loss', 'd_loss'}`; the
+generator/discriminator are written against dense/conv2d/deconv2d + arg_scope exactly as in
+the reference; variable names, loss definitions, per-step batch consumption
+((n_disc_train + 1) batches for wgan/iwgan) and the reference's *effective* semantics
+(no clipping, no BN moving averages, whole-batch penalty norm, last
+replica's losses reported).
+
+What is MI355X-native: D(x), D(g) and D(x_hat) run as ONE batched pass over a 3B-image
+buffer [x | g | x_hat] (the iwgan critic has no batch norm, so this is exact); the penalty's
+second-order term is the hand-derived tangent pass of engine.SeqNet.tangent_backward; all
+scalars stay on the device until the end of the step; gradients live in one flat bucket per net
+(one RCCL all-reduce + one fused optimizer launch).
+"""
+import torch
+
+from .. import _lib
+from .. import kernels as K
+from .. import engine
+from ..ops.layers import (dense, conv2d, deconv2d, flatten, reshape, random_normal, arg_scope,
+                          variable_scope, placeholder, reset_graph)
+from ..ops.activations import lrelu, relu, tanh, sigmoid
+from ..util import tower_scope_range, average_gradients, init_optimizer, collection_to_dict
+
+GP_LAMBDA = 10.0          # l_term, models/gan.py:199
+
+
+# ------------------------------------------------------------------------------ builders
+def generator(batch_size, latent_size, args, reuse=False):
+    """models/gan.py:234-254.  The reference hard-wires a 4x4 base and 64x64x3 output (:241,247-248);
+    the base is generalised to s0 = H/16 so 32x32 data needs no --resize;
+    --resize 64 64 reproduces the literal network."""
+    h, w, c = args.image_shape
+    s0h, s0w = h // 16, w // 16
+    output_dim = h * w * c
+    with arg_scope([dense, deconv2d], reuse=reuse, use_batch_norm=True, activation=relu):
+        z = random_normal([batch_size, latent_size])
+        y = dense(z, latent_size, s0h * s0w * 4 * latent_size, name='fc1')
+        y = reshape(y, [-1, s0h, s0w, 4 * latent_size])
+        y = deconv2d(y, 4 * latent_size, 2 * latent_size, 5, 2, name='dc1')
+        y = deconv2d(y, 2 * latent_size, latent_size, 5, 2, name='dc2')
+        y = deconv2d(y, latent_size, int(latent_size / 2), 5, 2, name='dc3')
+        y = deconv2d(y, int(latent_size / 2), c, 5, 2, name='dc4', activation=tanh, use_batch_norm=False)
+        y = reshape(y, [-1, output_dim])
+    return y
+
+
+def discriminator(x, args, reuse=False):
+    """models/gan.py:257-287 (the reshape to [-1, 4*4*4*L] is kept literally: SURVEY App. C-2)."""
+    use_bn = False if args.model == 'iwgan' else True
+    final_activation = None if args.model in ['wgan', 'iwgan'] else sigmoid
+    h, w, c = args.image_shape
+    with arg_scope([conv2d], use_batch_norm=use_bn, activation=lrelu, reuse=reuse):
+        x = reshape(x, [-1, h, w, c])
+        x = conv2d(x, c, args.latent_size, 5, 2, name='c1', use_batch_norm=False)
+        x = conv2d(x, args.latent_size, args.latent_size * 2, 5, 2, name='c2')
+        x = conv2d(x, args.latent_size * 2, args.latent_size * 4, 5, 2, name='c3')
+        x = reshape(x, [-1, 4 * 4 * 4 * args.latent_size])
+        x = dense(x, 4 * 4 * 4 * args.latent_size, 1, use_batch_norm=False, activation=final_activation,
+                  name='fc2', reuse=reuse)
+        x = reshape(x, [-1])
+    return x
+
+
+# ------------------------------------------------------------------------------ one replica
+class GanReplica:
+    """The per-GPU replica ("tower") of models/gan.py:55-70 plus its optimizers (:46,79-81)."""
+
+    # device scalar slots
+    S_DREAL, S_DFAKE, S_SUMSQ, S_GP, S_GPCOEF, S_GLOSS_AUX = 0, 1, 2, 3, 4, 5
+
+    def __init__(self, x_source, args, sess):
+        self.args, self.sess, self.x_source = args, sess, x_source
+        self.model = args.model
+        B, L = args.batch_size, args.latent_size
+        h, w, c = args.image_shape
+        dev, dt = sess.device, sess.dtype
+        self.B, self.img_elems = B, h * w * c
+        self.iwgan = self.model == 'iwgan'
+        self.display_d_loss = getattr(args, 'display_d_loss', True)
+        if self.model == 'gan':
+            raise NotImplementedError("--model gan (sigmoid log-loss) is not wired to the HIP path yet; use wgan/iwgan")
+
+        # ---- build the graph exactly as models/gan.py:55-63 does for one tower
+        reset_graph()
+        x_sym = placeholder((None, h * w * c))
+        for _x, scope, gpu_id in tower_scope_range(x_sym, args.n_gpus, B, sess):
+            with variable_scope('generator') as gnet:
+                g_sym = generator(B, L, args, reuse=False)
+            with variable_scope('discriminator') as dnet:
+                d_real = discriminator(_x, args, reuse=False)
+                d_fake = discriminator(g_sym, args, reuse=True)
+                if self.iwgan:                     # gradient_penalty's third pass (models/gan.py:227)
+                    d_hat = discriminator(placeholder((None, h * w * c)), args, reuse=True)
+        self.rows_per_image = d_real.rows_per_image
+        self.gnet, self.dnet = gnet, dnet
+
+        # ---- bind to HBM.  D input buffer holds the three passes: slot 0 = x, 1 = g, 2 = x_hat
+        self.nslots = 3 if self.iwgan else 2
+        self.ws = K.Workspace(dev)
+        self.d_store, self.g_store = engine.ParamStore(dev), engine.ParamStore(dev)
+        self.D = engine.SeqNet(dnet, self.nslots * B, (h, w, c), dt, dev, self.d_store,
+                               n_bn_passes=(1 if self.iwgan else 2), need_input_grad=True,
+                               tangent_capacity=(B if self.iwgan else 0), ws=self.ws)
+        # the generator writes straight into slot 1 and reads dL/dg from the same slot of D.dx
+        self.G = engine.SeqNet(gnet, B, (1, 1, L), dt, dev, self.g_store, ws=self.ws,
+                               out_act=self.D.x.view(B, B), out_grad=self.D.dx.view(B, B))
+        self.D.declare_variables()
+        self.G.declare_variables()
+        self.d_store.allocate()
+        self.g_store.allocate()
+        gen = torch.Generator().manual_seed(sess.seed)
+        self.G.init_variables(gen)
+        self.D.init_variables(gen)
+        self.g_opt, self.d_opt = init_optimizer(args, self.g_store), init_optimizer(args, self.d_store)   # :46
+        self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    # -- variables ---------------------------------------------------------------------------------
+    def refresh(self):
+        self.G.repack()
+        self.D.repack()
+
+    def load_variables(self, arrays):
+        self.g_store.load(arrays)
+        self.d_store.load(arrays)
+        self.refresh()
+
+    def variables(self):
+        d = self.g_store.state_dict()
+        d.update(self.d_store.state_dict())
+        return d
+
+    def gradients(self):
+        d = self.g_store.grads_dict()
+        d.update(self.d_store.grads_dict())
+        return d
+
+    # -- pieces ------------------------------------------------------------------------------------
+    def _load_real(self, x01):
+        """models/gan.py:49-50: x = 2 * (flatten(x) - 0.5) into slot 0."""
+        n = self.B * self.img_elems
+        if x01.dtype != torch.float32 or x01.numel() != n:
+            raise ValueError('expected a float32 batch of %d values in [0,1], got %s %s' % (n, x01.dtype, tuple(x01.shape)))
+        _lib.call('tdg_affine_cast', self.sess.dtype, K.ptr(x01.contiguous()), n, 2.0, -0.5, self.D.x.ptr(0), K.stream())
+
+    def _generate(self):
+        self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246
+        self.G.forward(0, self.B)                                      # g lands in D.x slot 1
+
+    def _interpolate(self):
+        """models/gan.py:224-226 into slot 2."""
+        B = self.B
+        self.sess.random_uniform(self.alpha, B, 'alpha')
+        _lib.call('tdg_gp_interp', self.sess.dtype, self.D.x.ptr(0), self.D.x.ptr(B), K.ptr(self.alpha), B,
+                  self.img_elems, self.D.x.ptr(2 * B), K.stream())
+
+    def _d_forward(self, first_slot, nslots):
+        B = self.B
+        if self.iwgan:
+            self.D.forward(first_slot * B, nslots * B)                 # BN-free critic: one batched pass
+        else:
+            for s in range(first_slot, first_slot + nslots):           # per-pass batch statistics and betas
+                self.D.forward(s * B, B, bn_pass=s)
+        return self.D.layers[-1].out
+
+    def _means(self, scores):
+        R = self.B * self.rows_per_image
+        _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
+        _lib.call('tdg_mean_f32', K.ptr(scores, 4 * R), R, K.ptr(self.scal, 4 * self.S_DFAKE), K.stream())
+
+    def _seed(self, slot, value):
+        R = self.B * self.rows_per_image
+        _lib.call('tdg_fill_f32', K.ptr(self.D.layers[-1].seed, 4 * slot * R), R, value, K.stream())
+
+    def _penalty_from_v(self):
+        """slopes = sqrt(sum over the WHOLE batch tensor) (models/gan.py:229), penalty (:230)."""
+        B = self.B
+        K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
+        _lib.call('tdg_gp_scalars', K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA, K.ptr(self.scal, 4 * self.S_GP), K.stream())
+
+    # -- steps -------------------------------------------------------------------------------------
+    def d_step(self, x01):
+        """One run of d_train_op (models/gan.py:152,171): d_loss gradients w.r.t. D, averaged, applied."""
+        B, R = self.B, self.B * self.rows_per_image
+        self._load_real(x01)
+        self._generate()
+        if self.iwgan:
+            self._interpolate()
+        scores = self._d_forward(0, self.nslots)
+        self._means(scores)
+        self._seed(0, -1.0 / R)                                       # d/d(d_real) of -mean(d_real)
+        self._seed(1, 1.0 / R)                                        # d/d(d_fake) of  mean(d_fake)
+        if self.iwgan:
+            self._seed(2, 1.0)                                        # tf.gradients(d_interpolates, ...) (:228)
+            self.D.backward(0, 3 * B, want_params=True, want_dx=True, param_images=(0, 2 * B), dx_images=(2 * B, B))
+            self._penalty_from_v()
+            # u = d(lambda * penalty)/dv = lambda * 2 (s-1)/s * v, then the tangent pass accumulates dW
+            _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
+                      K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
+            self.D.tangent_backward(2 * B, B, acc=True)
+        else:
+            self.D.backward(0, B, bn_pass=0, want_params=True, acc=False)
+            self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
+        self.sess.assert_finite(self.d_store, 'd_step')
+        scale = average_gradients(self.sess, self.d_store)            # models/gan.py:77
+        self.d_opt.step(scale)                                        # :81
+        self.sess.global_step += 1
+        self.D.repack()
+
+    def g_step(self, x01):
+        """One run of [g_train_op, losses] (models/gan.py:153,172)."""
+        B, R = self.B, self.B * self.rows_per_image
+        self._generate()
+        if self.display_d_loss:
+            self._load_real(x01)
+            if self.iwgan:
+                self._interpolate()
+            scores = self._d_forward(0, self.nslots)
+        else:
+            scores = self._d_forward(1, 1)
+        self._means(scores)
+        self._seed(1, -1.0 / R)                                       # d/d(d_fake) of g_loss = -mean(d_fake)
+        if self.iwgan and self.display_d_loss:
+            self._seed(2, 1.0)
+            self.D.backward(B, 2 * B, want_params=False, want_dx=True)
+            self._penalty_from_v()
+        else:
+            self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
+        self.G.backward(0, B, want_params=True)                       # seed = D.dx slot 1 (aliased)
+        self.sess.assert_finite(self.g_store, 'g_step')
+        scale = average_gradients(self.sess, self.g_store)            # models/gan.py:76
+        self.g_opt.step(scale)                                        # :80
+        self.sess.global_step += 1
+        self.G.repack()
+
+    def losses(self):
+        """Host read-back of the device scalars (one sync): models/gan.py:196-205."""
+        s = self.scal.cpu().tolist()
+        g_loss = -s[self.S_DFAKE]
+        d_loss = s[self.S_DFAKE] - s[self.S_DREAL]
+        if self.iwgan:
+            d_loss += GP_LAMBDA * s[self.S_GP]
+        return collection_to_dict([('tower_%d/g_loss:0' % self.sess.rank, g_loss),
+                                   ('tower_%d/d_loss:0' % self.sess.rank, d_loss)])
+
+    def train_func(self, sess=None, args=None):
+        """_train_wgan / _train_iwgan helper (models/gan.py:150-155,169-173): n_disc_train D steps,
+        then one G step, each on a fresh batch; returns the loss dict of the G step's batch."""
+        args = args or self.args
+        for _ in range(args.n_disc_train):
+            self.d_step(self.x_source.next_batch())
+        self.g_step(self.x_source.next_batch())
+        return self.losses()
+
+
+def gan(x, args, sess=None):
+    """models/gan.py:39-91.  `x` is the per-replica input source (`.next_batch()` -> device float32
+    [B, H, W, C] in [0,1]); returns the training function train.py:246,307 expects."""
+    from ..runtime import Session
+    sess = sess or Session(dtype=getattr(args, 'dtype_code', K.BF16), seed=getattr(args, 'seed', 0) or 0)
+    replica = GanReplica(x, args, sess)
+
+    def train_func(sess_=None, args_=None):
+        return replica.train_func(sess_, args_)
+    train_func.replica = replica
+    return train_func

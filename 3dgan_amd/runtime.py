@@ -1,0 +1,108 @@
+"""Runtime context that plays the role of the reference's `sess` (tf.Session under
+tf.train.Supervisor, train.py:254-273): device, replica identity, compute dtype, the
+counter-based RNG streams that replace TF's unseeded Philox ops, and the gradient exchange
+that replaces the CPU-side tower mean of util.py:118-147.
+
+One process per GPU: rank r is tower r of the reference (util.py:54-77); weights and optimizer
+state are replicated in every GPU's HBM, gradients are averaged with one RCCL all-reduce per
+net on the flat f32 bucket (torch.distributed backend "nccl" = RCCL over xGMI).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from . import kernels as K
+
+
+class Session:
+    def __init__(self, device=None, dtype=K.BF16, seed=0, rank=None, world_size=None, check_numerics=False):
+        if rank is None:
+            rank = int(os.environ.get('RANK', '0'))
+        if world_size is None:
+            world_size = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank, self.world_size = rank, world_size
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _lib.TdgError('no MI355X visible: the 3dgan_amd hot path has no CPU fallback')
+            device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+        self.device = torch.device(device)
+        if self.device.type == 'cuda':
+            torch.cuda.set_device(self.device)
+        _lib.load()                                  # fail loudly now if the HIP library is missing
+        self.dtype = dtype
+        self.seed = int(seed)
+        self.check_numerics = check_numerics
+        self.global_step = 0                         # train.py:201 (bumped by BOTH apply ops, gan.py:79-81)
+        self.global_epoch = 0                        # train.py:202
+        self._draws = 0
+        self.inject = {}                             # tests: {'z': [..], 'alpha': [..]} consumed in order
+        self._flag = None
+
+    # ---- RNG (tf.random_normal / tf.random_uniform, models/gan.py:246,224) ---------
+    def _next_offset(self):
+        self._draws += 1
+        return self._draws << 24
+
+    def _injected(self, key):
+        q = self.inject.get(key)
+        if q:
+            return q.pop(0)
+        return None
+
+    def random_normal(self, act, n_rows, key='z'):
+        """Fill the first n_rows images of `act` with N(0,1) (per-replica stream)."""
+        inj = self._injected(key)
+        n = n_rows * act.image_elems
+        if inj is not None:
+            t = torch.as_tensor(inj, dtype=torch.float32).reshape(-1)
+            act.buf[:n].copy_(t.to(self.device, K.TORCH_DTYPE[act.dtype]))
+            return
+        _lib.call('tdg_random_normal', act.dtype, self.seed, (self.rank << 8) | 1, self._next_offset(), n,
+                  act.ptr(0), K.stream())
+
+    def random_uniform(self, out, n, key='alpha'):
+        inj = self._injected(key)
+        if inj is not None:
+            out[:n].copy_(torch.as_tensor(inj, dtype=torch.float32).reshape(-1).to(self.device))
+            return
+        _lib.call('tdg_random_uniform_f32', self.seed, (self.rank << 8) | 2, self._next_offset(), n, K.ptr(out), K.stream())
+
+    # ---- gradient exchange (util.py:118-147 average_gradients) ---------------------------------------
+    def allreduce_mean_scale(self, flat_grads):
+        """Sum the flat bucket over replicas; returns the 1/n the optimizer kernel applies."""
+        if self.world_size > 1:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+            return 1.0 / self.world_size
+        return 1.0
+
+    def assert_finite(self, store, what):
+        """--check_numerics (hem/util/training.py:52-53): name the offending variable."""
+        if not self.check_numerics:
+            return
+        if self._flag is None:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._flag.zero_()
+        _lib.call('tdg_check_finite', K.ptr(store.grads), store.size, K.ptr(self._flag), K.stream())
+        if int(self._flag.item()):
+            for name, gv in store.grad_views.items():
+                if not bool(torch.isfinite(gv).all()):
+                    raise FloatingPointError('%s: gradient of %s has NaN or Inf' % (what, name))
+
+
+def init_distributed(backend=None):
+    """Join the process group when launched by torch.distributed.run (RANK/WORLD_SIZE set)."""
+    ws = int(os.environ.get('WORLD_SIZE', '1'))
+    if ws > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend=backend)
+    return ws
+
+
+def broadcast_store(store, src=0):
+    """Replicas start from identical variables (shared variables of the reference's towers)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(store.params, src=src)

@@ -1,0 +1,67 @@
+"""Replica / optimizer / reporting utilities with the names of the reference's `util.py`
+(tower_scope_range :54-77, average_gradients :118-147, init_optimizer :150-183,
+collection_to_dict :187-193, format_for_terminal :196-212)."""
+from . import engine
+from .ops.input import batch_slice
+
+
+def tower_scope_range(x, n_gpus, batch_size, session=None):
+    """util.py:54-77.  The reference yields one (slice, scope, gpu_id) per in-graph tower; here
+    each process is exactly one tower, so the generator yields once with this rank's id.
+    `x` may be a global batch (sliced like ops/input.py:24) or a per-rank source."""
+    rank = session.rank if session is not None else 0
+    if hasattr(x, 'shape') and x.shape[0] == batch_size * max(n_gpus, 1):
+        x = batch_slice(x, batch_size, rank)
+    yield x, 'tower_%d' % rank, rank
+
+
+def average_gradients(session, store):
+    """util.py:118-147: mean over towers of every gradient == all-reduce(sum) / n on the flat
+    bucket; the division is folded into the optimizer kernel.  Returns that scale."""
+    return session.allreduce_mean_scale(store.grads)
+
+
+def init_optimizer(args, store):
+    """util.py:150-183 (adadelta/adagrad/ftrl/proximal variants are out of scope)."""
+    o = args.optimizer
+    if o == 'rmsprop':
+        return engine.RMSProp(store, args.lr, decay=args.decay, momentum=args.momentum, centered=args.centered)
+    if o == 'adam':
+        return engine.Adam(store, args.lr, args.beta1, args.beta2)
+    if o == 'momentum':
+        return engine.Momentum(store, args.lr, args.momentum)
+    if o == 'sgd':
+        return engine.Momentum(store, args.lr, 0.0)
+    if o == 'pgd':
+        return None                    # the reference forgets the `return` (util.py:171-172)
+    raise NotImplementedError('optimizer %r is not available in this build' % o)
+
+
+def collection_to_dict(collection):
+    """util.py:187-193: key = last path component of the tensor name, ':0' stripped."""
+    d = {}
+    for c in collection:
+        name, value = (c.name, c) if hasattr(c, 'name') else c
+        d[name.split('/')[-1].split(':')[0]] = value
+    return d
+
+
+def format_for_terminal(results, prev_results):
+    """util.py:196-212 (including its first-call quirk of formatting in place)."""
+    if not prev_results:
+        disp_results = results
+        for k in disp_results:
+            disp_results[k] = '{:3f}'.format(disp_results[k])
+    else:
+        disp_results = {}
+        for k in prev_results:
+            diff = float(results[k]) - float(prev_results[k])
+            sym = '+' if diff > 0 else ('-' if diff < 0 else '~')
+            disp_results[k] = '{:3f}({})'.format(results[k], sym)
+    return disp_results
+
+
+def chunks(x, n):
+    """hem/util/misc.py chunks (pinned by hem/util/test_misc.py:22-30)."""
+    for i in range(0, len(x), n):
+        yield x[i:i + n]
