@@ -52,18 +52,25 @@ __device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
 }
 
 // ============================================================================ column reductions
-// partial[blk][v][c] = sum over the block's rows of f_v(row, c), v < NV
+// partial[blk][v][c] = sum over the block's rows of f_v(row, c), v < 2.  2-D grid: blockIdx.x walks
+// row blocks, blockIdx.y walks column chunks of CL*VW channels; each lane owns VW consecutive
+// channels (one 8/16-byte load per row when VW = 4).
 struct ColGeom {
-  int rows, C, cs, nblk, rows_per_blk, CL;  // CL = channel lanes (power of two <= 64)
+  int rows, C, cs, nblk, rows_per_blk, CL, ncol, vw;  // CL = channel lanes (power of two <= 64)
 };
-static inline ColGeom col_geom(int rows, int C, int cs) {
+static inline ColGeom col_geom(int rows, int C, int cs, const void* p0 = nullptr, const void* p1 = nullptr, int es = 4) {
   ColGeom g;
   g.rows = rows; g.C = C; g.cs = cs;
+  const bool al = (((uintptr_t)p0 | (uintptr_t)p1) % (4 * es)) == 0;
+  g.vw = (C % 4 == 0 && cs % 4 == 0 && al) ? 4 : 1;
+  const int cv = (C + g.vw - 1) / g.vw;
   int cl = 1;
-  while (cl < C && cl < 64) cl <<= 1;
+  while (cl < cv && cl < 64) cl <<= 1;
   g.CL = cl;
+  g.ncol = (cv + cl - 1) / cl;
   int nblk = (rows + 127) / 128;
-  if (nblk > 256) nblk = 256;
+  const int cap = g.ncol >= 8 ? 32 : 256;
+  if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   g.rows_per_blk = (rows + nblk - 1) / nblk;
   g.nblk = (rows + g.rows_per_blk - 1) / g.rows_per_blk;
@@ -81,50 +88,80 @@ struct ColArgs {
   float* partial;
 };
 
-template <typename T, int MODE>
+template <typename T, int VW>
+__device__ __forceinline__ void load_vw(const T* p, float (&v)[VW]) {
+  if constexpr (VW == 1) {
+    v[0] = to_f32<T>(p[0]);
+  } else if constexpr (sizeof(T) == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  } else {
+    const bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (float)t[e];
+  }
+}
+
+template <typename T, int MODE, int VW>
 __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const ColArgs a) {
-  __shared__ float sh[2][256];
+  __shared__ float sh[2][VW][256];
   const int CL = g.CL, RL = 256 / CL;
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int r0 = blockIdx.x * g.rows_per_blk;
   const int r1 = min(g.rows, r0 + g.rows_per_blk);
   const T* x = static_cast<const T*>(a.x);
   const T* y = static_cast<const T*>(a.y);
-  for (int c0 = 0; c0 < g.C; c0 += CL) {
-    const int c = c0 + tx;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < g.C) {
-      float pivot = 0.f, bta = 0.f;
-      if (MODE == COL_BN_STATS) pivot = to_f32<T>(x[c]);
-      if (MODE == COL_BN_BWD) bta = a.beta[c];
-      for (int r = r0 + ty; r < r1; r += RL) {
-        const size_t i = (size_t)r * g.cs + c;
-        const float v = to_f32<T>(x[i]);
-        if (MODE == COL_BN_STATS) {
-          const float d = v - pivot;
-          s0 += d; s1 += d * d;
-        } else if (MODE == COL_BN_BWD) {
-          const float pre = to_f32<T>(y[i]);
-          const float dpre = v * (a.act == TDG_ACT_RELU ? (pre > 0.f ? 1.f : 0.f)
-                                  : a.act == TDG_ACT_LRELU ? (pre > 0.f ? 1.f : a.leak) : 1.f);
-          s0 += dpre; s1 += dpre * (pre - bta);
-        } else if (MODE == COL_SUM) {
-          s0 += v;
-        } else {
-          s0 += v * (a.coef ? a.coef[r] : 1.f);
+  const int c = (blockIdx.y * CL + tx) * VW;
+  float s0[VW], s1[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) s0[e] = s1[e] = 0.f;
+  if (c < g.C) {
+    float pivot[VW], bta[VW];
+#pragma unroll
+    for (int e = 0; e < VW; ++e) pivot[e] = bta[e] = 0.f;
+    if (MODE == COL_BN_STATS) load_vw<T, VW>(x + c, pivot);
+    if (MODE == COL_BN_BWD) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) bta[e] = a.beta[c + e];
+    }
+    for (int r = r0 + ty; r < r1; r += RL) {
+      const size_t i = (size_t)r * g.cs + c;
+      float v[VW];
+      load_vw<T, VW>(x + i, v);
+      if (MODE == COL_BN_STATS) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) { const float d = v[e] - pivot[e]; s0[e] += d; s1[e] += d * d; }
+      } else if (MODE == COL_BN_BWD) {
+        float pre[VW];
+        load_vw<T, VW>(y + i, pre);
+#pragma unroll
+        for (int e = 0; e < VW; ++e) {
+          const float dpre = v[e] * (a.act == TDG_ACT_RELU ? (pre[e] > 0.f ? 1.f : 0.f)
+                                     : a.act == TDG_ACT_LRELU ? (pre[e] > 0.f ? 1.f : a.leak) : 1.f);
+          s0[e] += dpre; s1[e] += dpre * (pre[e] - bta[e]);
         }
+      } else if (MODE == COL_SUM) {
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s0[e] += v[e];
+      } else {
+        const float k = a.coef ? a.coef[r] : 1.f;
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s0[e] += v[e] * k;
       }
     }
-    sh[0][threadIdx.x] = s0;
-    sh[1][threadIdx.x] = s1;
-    __syncthreads();
-    if (ty == 0 && c < g.C) {
+  }
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { sh[0][e][threadIdx.x] = s0[e]; sh[1][e][threadIdx.x] = s1[e]; }
+  __syncthreads();
+  if (ty == 0 && c < g.C) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
       float t0 = 0.f, t1 = 0.f;
-      for (int k = 0; k < RL; ++k) { t0 += sh[0][k * CL + tx]; t1 += sh[1][k * CL + tx]; }
-      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c] = t0;
-      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c] = t1;
+      for (int k = 0; k < RL; ++k) { t0 += sh[0][e][k * CL + tx]; t1 += sh[1][e][k * CL + tx]; }
+      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c + e] = t0;
+      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c + e] = t1;
     }
-    __syncthreads();
   }
 }
 
@@ -138,15 +175,25 @@ struct FinArgs {
   float* out1;          // bwd: mean sums [2][C] for the apply pass
   float beta_acc;
 };
+// 32 channels x 8 partial lanes per block; fixed summation order (deterministic)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.C) return;
+  __shared__ float sh[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   float s0 = 0.f, s1 = 0.f;
-  for (int b = 0; b < a.nblk; ++b) {
-    s0 += a.partial[((size_t)b * 2 + 0) * a.C + c];
-    s1 += a.partial[((size_t)b * 2 + 1) * a.C + c];
-  }
+  if (c < a.C)
+    for (int b = ty; b < a.nblk; b += 8) {
+      s0 += a.partial[((size_t)b * 2 + 0) * a.C + c];
+      s1 += a.partial[((size_t)b * 2 + 1) * a.C + c];
+    }
+  sh[0][ty][tx] = s0;
+  sh[1][ty][tx] = s1;
+  __syncthreads();
+  if (ty != 0 || c >= a.C) return;
+  s0 = s1 = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
   const float inv = 1.f / (float)a.rows;
   if (MODE == FIN_BN_STATS) {
     const float pivot = to_f32<T>(static_cast<const T*>(a.x0)[c]);
@@ -163,46 +210,84 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const T* __restrict__ u, int rows, int C, int cs,
-                                                          const float* __restrict__ beta, const float* __restrict__ stats,
-                                                          int act, float leak, T* __restrict__ pre, T* __restrict__ h) {
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mean = stats[c], rstd = stats[C + c], b = beta[c];
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-      const size_t i = (size_t)r * cs + c;
-      const float p = (to_f32<T>(u[i]) - mean) * rstd + b;
-      pre[i] = from_f32<T>(p);
-      h[i] = from_f32<T>(apply_act(p, act, leak));
-    }
+template <typename T, int VW>
+__device__ __forceinline__ void store_vw(T* p, const float (&v)[VW]) {
+  if constexpr (VW == 1) {
+    p[0] = from_f32<T>(v[0]);
+  } else if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+  } else {
+    *reinterpret_cast<bf16x4*>(p) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
   }
 }
 
-template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const T* __restrict__ dh, const T* __restrict__ pre, int rows, int C,
-                                                          int cs, const float* __restrict__ beta, const float* __restrict__ stats,
-                                                          const float* __restrict__ sums, int act, float leak, T* __restrict__ du) {
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float rstd = stats[C + c], b = beta[c], m0 = sums[c], m1 = sums[C + c];
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-      const size_t i = (size_t)r * cs + c;
-      const float p = to_f32<T>(pre[i]);
-      const float f = act == TDG_ACT_RELU ? (p > 0.f ? 1.f : 0.f) : act == TDG_ACT_LRELU ? (p > 0.f ? 1.f : leak) : 1.f;
-      const float dpre = to_f32<T>(dh[i]) * f;
-      du[i] = from_f32<T>(rstd * (dpre - m0 - (p - b) * m1));
-    }
+// lanes: CL channel lanes (VW channels each) x 256/CL row lanes; blockIdx.y = column chunk
+template <typename T, int VW>
+__global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, const T* __restrict__ u,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          int act, float leak, T* __restrict__ pre, T* __restrict__ h) {
+  const int CL = g.CL, RL = 256 / CL, C = g.C;
+  const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
+  const int c = (blockIdx.y * CL + tx) * VW;
+  if (c >= C) return;
+  float mean[VW], rstd[VW], b[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { mean[e] = stats[c + e]; rstd[e] = stats[C + c + e]; b[e] = beta[c + e]; }
+  for (int r = blockIdx.x * RL + ty; r < g.rows; r += gridDim.x * RL) {
+    const size_t i = (size_t)r * g.cs + c;
+    float v[VW], p[VW], a[VW];
+    load_vw<T, VW>(u + i, v);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) { p[e] = (v[e] - mean[e]) * rstd[e] + b[e]; a[e] = apply_act(p[e], act, leak); }
+    store_vw<T, VW>(pre + i, p);
+    store_vw<T, VW>(h + i, a);
   }
+}
+
+template <typename T, int VW>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, const T* __restrict__ dh, const T* __restrict__ pre,
+                                                          const float* __restrict__ beta, const float* __restrict__ stats,
+                                                          const float* __restrict__ sums, int act, float leak, T* __restrict__ du) {
+  const int CL = g.CL, RL = 256 / CL, C = g.C;
+  const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
+  const int c = (blockIdx.y * CL + tx) * VW;
+  if (c >= C) return;
+  float rstd[VW], b[VW], m0[VW], m1[VW];
+#pragma unroll
+  for (int e = 0; e < VW; ++e) { rstd[e] = stats[C + c + e]; b[e] = beta[c + e]; m0[e] = sums[c + e]; m1[e] = sums[C + c + e]; }
+  for (int r = blockIdx.x * RL + ty; r < g.rows; r += gridDim.x * RL) {
+    const size_t i = (size_t)r * g.cs + c;
+    float d[VW], p[VW], o[VW];
+    load_vw<T, VW>(dh + i, d);
+    load_vw<T, VW>(pre + i, p);
+#pragma unroll
+    for (int e = 0; e < VW; ++e) {
+      const float f = act == TDG_ACT_RELU ? (p[e] > 0.f ? 1.f : 0.f) : act == TDG_ACT_LRELU ? (p[e] > 0.f ? 1.f : leak) : 1.f;
+      o[e] = rstd[e] * (d[e] * f - m0[e] - (p[e] - b[e]) * m1[e]);
+    }
+    store_vw<T, VW>(du + i, o);
+  }
+}
+
+static inline int apply_row_blocks(const ColGeom& g) {
+  const int rl = 256 / g.CL;
+  int nb = (g.rows + rl * 8 - 1) / (rl * 8);
+  const int cap = 2048 / g.ncol > 1 ? 2048 / g.ncol : 1;
+  return nb < 1 ? 1 : (nb > cap ? cap : nb);
 }
 
 extern "C" size_t tdg_bn_workspace_bytes(int rows, int c) {
-  const ColGeom g = col_geom(rows, c, c);
-  return ((size_t)g.nblk * 2 * c + 2 * (size_t)c) * sizeof(float);
+  (void)rows;
+  return ((size_t)256 * 2 * c + 2 * (size_t)c) * sizeof(float);   // upper bound on the row blocks
 }
 extern "C" size_t tdg_colsum_workspace_bytes(int rows, int cols) { return tdg_bn_workspace_bytes(rows, cols); }
 
 template <typename T, int MODE>
 static int run_col_partial(const ColGeom& g, const ColArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL((col_partial_kernel<T, MODE>), dim3(g.nblk), dim3(256), 0, s, g, a);
+  if (g.vw == 4)
+    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 4>), dim3(g.nblk, g.ncol), dim3(256), 0, s, g, a);
+  else
+    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 1>), dim3(g.nblk, g.ncol), dim3(256), 0, s, g, a);
   TDG_HIP_LAUNCH_CHECK("col_partial");
   return TDG_OK;
 }
@@ -214,18 +299,23 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
   TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_fwd: bad shape rows=%d c=%d cs=%d", rows, c, cs);
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_fwd: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const ColGeom g = col_geom(rows, c, cs);
+  const ColGeom g = col_geom(rows, c, cs, u, nullptr, tdg_dtype_size(dtype));
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = u; a.partial = static_cast<float*>(workspace);
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.x0 = u; f.eps = eps; f.out0 = stats;
-  const int ablocks = rows < 2048 ? rows : 2048;
+  ColGeom ga = col_geom(rows, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), tdg_dtype_size(dtype));
+  const dim3 agrid(apply_row_blocks(ga), ga.ncol);
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_STATS>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + 255) / 256), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(bn_fwd_apply_kernel<T>, dim3(ablocks), dim3(256), 0, s, static_cast<const T*>(u), rows, c, cs, beta,
-                       stats, act, leak, static_cast<T*>(pre), static_cast<T*>(h));
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + 31) / 32), dim3(256), 0, s, f);
+    if (ga.vw == 4)
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h));
+    else
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h));
   })
   TDG_HIP_LAUNCH_CHECK("bn_fwd");
   return TDG_OK;
@@ -238,19 +328,24 @@ extern "C" int tdg_bn_bwd(int dtype, const void* dh, const void* pre, int rows, 
   TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_bwd: bad shape");
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_bwd: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const ColGeom g = col_geom(rows, c, cs);
+  const ColGeom g = col_geom(rows, c, cs, dh, pre, tdg_dtype_size(dtype));
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = dh; a.y = pre; a.beta = beta; a.act = act; a.leak = leak; a.partial = static_cast<float*>(workspace);
   float* sums = a.partial + (size_t)g.nblk * 2 * c;
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.out0 = dbeta; f.out1 = sums; f.beta_acc = beta_acc;
-  const int ablocks = rows < 2048 ? rows : 2048;
+  ColGeom ga = col_geom(rows, c, cs, dh, (const void*)((uintptr_t)pre | (uintptr_t)du), tdg_dtype_size(dtype));
+  const dim3 agrid(apply_row_blocks(ga), ga.ncol);
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + 255) / 256), dim3(256), 0, s, f);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ablocks), dim3(256), 0, s, static_cast<const T*>(dh),
-                       static_cast<const T*>(pre), rows, c, cs, beta, stats, sums, act, leak, static_cast<T*>(du));
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + 31) / 32), dim3(256), 0, s, f);
+    if (ga.vw == 4)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh),
+                         static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh),
+                         static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
   })
   TDG_HIP_LAUNCH_CHECK("bn_bwd");
   return TDG_OK;
@@ -261,7 +356,7 @@ extern "C" int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs,
   TDG_CHECK_ARG(dy && db && workspace && rows > 0 && c > 0 && cs >= c, "tdg_bias_grad: bad argument");
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bias_grad: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const ColGeom g = col_geom(rows, c, cs);
+  const ColGeom g = col_geom(rows, c, cs, dy, nullptr, tdg_dtype_size(dtype));
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = dy; a.partial = static_cast<float*>(workspace);
   FinArgs f; memset(&f, 0, sizeof(f));
@@ -269,7 +364,7 @@ extern "C" int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_SUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + 255) / 256), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + 31) / 32), dim3(256), 0, s, f);
   })
   TDG_HIP_LAUNCH_CHECK("bias_grad");
   return TDG_OK;
@@ -280,7 +375,7 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
   TDG_CHECK_ARG(x && dw && workspace && rows > 0 && cols > 0 && cs >= cols, "tdg_colsum_weighted: bad argument");
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, cols)) { tdg_set_error("tdg_colsum_weighted: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const ColGeom g = col_geom(rows, cols, cs);
+  const ColGeom g = col_geom(rows, cols, cs, x, nullptr, tdg_dtype_size(dtype));
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = x; a.coef = coef; a.partial = static_cast<float*>(workspace);
   FinArgs f; memset(&f, 0, sizeof(f));
@@ -288,7 +383,7 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_WSUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + 255) / 256), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + 31) / 32), dim3(256), 0, s, f);
   })
   TDG_HIP_LAUNCH_CHECK("colsum_weighted");
   return TDG_OK;

@@ -546,23 +546,25 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const WgArgs args) 
   }
 }
 
-// dw[i] = beta*dw[i] + sum_z slabs[z][i]   (fixed summation order)
+// dw[i] = beta*dw[i] + sum_z slabs[z][i]   (fixed summation order: 16 z-lanes, then lane order)
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                          size_t n, int nsplit, size_t stride, float beta) {
-  const size_t n4 = n >> 2;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-    f32x4 s = *reinterpret_cast<const f32x4*>(slabs + 4 * i);
-    for (int z = 1; z < nsplit; ++z) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * stride + 4 * i);
-    if (beta != 0.f) s += beta * *reinterpret_cast<const f32x4*>(dw + 4 * i);
-    *reinterpret_cast<f32x4*>(dw + 4 * i) = s;
-  }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-    const size_t i = (n4 << 2) + threadIdx.x;
-    float s = slabs[i];
-    for (int z = 1; z < nsplit; ++z) s += slabs[(size_t)z * stride + i];
-    if (beta != 0.f) s += beta * dw[i];
-    dw[i] = s;
-  }
+  __shared__ f32x4 sh[16][16];
+  const int tx = threadIdx.x & 15, tz = threadIdx.x >> 4;
+  const size_t n4 = (n + 3) >> 2;                      // slabs are padded to a multiple of 4 floats
+  const size_t i = (size_t)blockIdx.x * 16 + tx;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < n4)
+    for (int z = tz; z < nsplit; z += 16) s += *reinterpret_cast<const f32x4*>(slabs + (size_t)z * stride + 4 * i);
+  sh[tz][tx] = s;
+  __syncthreads();
+  if (tz != 0 || i >= n4) return;
+  s = sh[0][tx];
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += sh[k][tx];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (4 * i + e < n) dw[4 * i + e] = (beta != 0.f ? beta * dw[4 * i + e] : 0.f) + s[e];
 }
 
 // ============================================================================================
@@ -991,7 +993,7 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
                             : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
   const size_t n = (size_t)a.ntaps * d->c * d->k;
-  const int blocks = (int)(n / 4 / 256 + 1 > 2048 ? 2048 : n / 4 / 256 + 1);
+  const int blocks = (int)(((n + 3) / 4 + 15) / 16);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.slabs, dw, n, a.nsplit,
                      (size_t)a.slab_stride, beta);
   TDG_HIP_LAUNCH_CHECK("slab_reduce");

@@ -88,6 +88,32 @@ def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=No
     return e
 
 
+class GemmTimer:
+    """Optional HIP-event timing of the conv GEMM launches (bench.py roofline): events are
+    recorded on torch's current stream, which is the stream every kernel is launched on."""
+
+    def __init__(self):
+        self.records = []          # (kind, start_event, end_event, flops)
+
+    def wrap(self, kind, flops, fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        self.records.append((kind, a, b, flops))
+
+    def summary(self):
+        """{kind: (launches, total_ms, total_flops)} -- call after a synchronize."""
+        out = {}
+        for kind, a, b, fl in self.records:
+            n, ms, f = out.get(kind, (0, 0.0, 0.0))
+            out[kind] = (n + 1, ms + a.elapsed_time(b), f + fl)
+        return out
+
+
+TIMER = None       # set to a GemmTimer to time conv GEMM launches
+
+
 class Conv:
     """One strided conv of the model: owns the packed filter operands and the split-K
     workspace; exposes the three GEMM forms of include/tdg.h."""
@@ -119,18 +145,34 @@ class Conv:
         if bwd:
             _lib.call('tdg_pack_filter_bwd', C.byref(self.desc), ptr(w), ptr(self.w_bwd), stream())
 
+    def flops(self, n_images):
+        """Algorithmic FLOPs of any of the three GEMM forms on n_images (2 x MACs, padding taps counted)."""
+        d = self.desc
+        return 2.0 * n_images * d.oh * d.ow * d.kh * d.kw * d.c * d.k
+
+    def _tag(self, form):
+        d = self.desc
+        return '%s/%s/%dx%d_c%d_k%d' % (form, 'bf16' if d.dtype == BF16 else 'f32', d.kh, d.kw, d.c, d.k)
+
     def fwd(self, x_ptr, y_ptr, n_images, epi=None):
-        _lib.call('tdg_conv2d_fwd', C.byref(self.desc), n_images, x_ptr, ptr(self.w_fwd), y_ptr,
-                  C.byref(epi) if epi is not None else None, stream())
+        def go():
+            _lib.call('tdg_conv2d_fwd', C.byref(self.desc), n_images, x_ptr, ptr(self.w_fwd), y_ptr,
+                      C.byref(epi) if epi is not None else None, stream())
+        TIMER.wrap(self._tag('fwd'), self.flops(n_images), go) if TIMER is not None else go()
 
     def bwd_data(self, y_ptr, x_ptr, n_images, epi=None):
-        _lib.call('tdg_conv2d_bwd_data', C.byref(self.desc), n_images, y_ptr, ptr(self.w_bwd), x_ptr,
-                  C.byref(epi) if epi is not None else None, stream())
+        def go():
+            _lib.call('tdg_conv2d_bwd_data', C.byref(self.desc), n_images, y_ptr, ptr(self.w_bwd), x_ptr,
+                      C.byref(epi) if epi is not None else None, stream())
+        TIMER.wrap(self._tag('bwd_data'), self.flops(n_images), go) if TIMER is not None else go()
 
     def bwd_filter(self, x_ptr, y_ptr, dw, n_images, beta=0.0):
         ws = self.workspace()
-        _lib.call('tdg_conv2d_bwd_filter', C.byref(self.desc), n_images, x_ptr, y_ptr, ptr(dw), beta,
-                  ptr(ws), ws.numel(), stream())
+
+        def go():
+            _lib.call('tdg_conv2d_bwd_filter', C.byref(self.desc), n_images, x_ptr, y_ptr, ptr(dw), beta,
+                      ptr(ws), ws.numel(), stream())
+        TIMER.wrap(self._tag('bwd_filter'), self.flops(n_images), go) if TIMER is not None else go()
 
 
 class Workspace:

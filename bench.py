@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec (whole node) of CIFAR-10-shaped IWGAN training, bs=512 per
+GPU (BASELINE.json metric).
+
+One "step" = one `train_func` call = n_disc_train (5) discriminator steps + 1 generator step
+on 6 fresh synthetic batches (models/gan.py:169-173), optimizer steps included;
+images/sec = steps/s x B x n_gpus (the reference's own progress unit, train.py:298).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant
+conv GEMM kernel, HIP-event timed inside the timed region) and `cpu_baseline` (the oracle's
+torch-autograd port on the host cores, bounded sample, rank 0 at N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# IWGAN 32x32x3, L=200, reference-faithful variant (G step re-evaluates d_loss): SURVEY 8d / BASELINE.md s.2
+GFLOP_PER_IMAGE_ITERATION = 30.08
+PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}        # MI355X_MICROARCH.md, dense
+
+
+def cpu_baseline(args):
+    """The oracle's autograd port of the identical iteration on the host cores (kind "port")."""
+    from oracle import gan_ref as G, torch_ref as TR
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))       # the GPU box grants a 16-core share per GPU
+    torch.set_num_threads(cores)
+    B = args.cpu_batch
+    cfg = G.make_cfg('iwgan', (32, 32, 3), args.latent_size, B)
+    P = TR.to_torch(G.init_params(cfg, 0, np.float32))
+    a = SimpleNamespace(optimizer='adam', lr=1e-4, beta1=0.5, beta2=0.9, n_disc_train=5)
+    tr = TR.TorchGanTrainer(P, cfg, a)
+    rng = np.random.default_rng(1234)
+
+    def inputs():
+        bs = [torch.tensor(rng.integers(0, 256, (B, 32, 32, 3)).astype(np.float32) / 255.0) for _ in range(6)]
+        zs = [torch.randn(B, args.latent_size) for _ in range(6)]
+        als = [torch.rand(B, 1) for _ in range(6)]
+        return bs, zs, als
+    tr.d_step(*[v[0] for v in inputs()])           # untimed warm-up (allocator, thread pool)
+    t0 = time.time()
+    tr.train_func(*inputs())
+    dt = time.time() - t0
+    return {'value': B / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '1 iteration (5 D + 1 G steps) at batch %d, f32 torch-autograd port of the oracle, %d threads '
+                      '(CPU restatement, not TensorFlow)' % (B, cores)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch_size', type=int, default=512)
+    ap.add_argument('--latent_size', type=int, default=200)
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--model', default='iwgan')
+    ap.add_argument('--cpu_batch', type=int, default=32)
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--no_kernel_timer', action='store_true')
+    args = ap.parse_args()
+
+    rt = importlib.import_module('3dgan_amd.runtime')
+    K = importlib.import_module('3dgan_amd.kernels')
+    gan = importlib.import_module('3dgan_amd.models.gan')
+    data = importlib.import_module('3dgan_amd.data')
+
+    world = rt.init_distributed()
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
+                         % (args.gpus, world, args.gpus))
+    sess = rt.Session(dtype=K.BF16 if args.dtype == 'bf16' else K.F32, seed=0)
+    margs = SimpleNamespace(model=args.model, batch_size=args.batch_size, latent_size=args.latent_size,
+                            image_shape=(32, 32, 3), n_gpus=args.gpus, optimizer='adam', lr=1e-4, beta1=0.5,
+                            beta2=0.9, decay=0.9, momentum=0.01, centered=False, n_disc_train=5,
+                            display_d_loss=True)              # examples/iwgan.config
+    src = data.SyntheticSource(12 * args.batch_size, margs.image_shape, args.batch_size, sess.device, 1234, sess.rank)
+    rep = gan.GanReplica(src, margs, sess)
+    rt.broadcast_store(rep.g_store)
+    rt.broadcast_store(rep.d_store)
+    rep.refresh()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rep.train_func()
+    timer = None
+    if not args.no_kernel_timer and sess.rank == 0:
+        timer = K.TIMER = K.GemmTimer()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        status = rep.train_func()
+    sync()
+    dt = time.perf_counter() - t0
+    K.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=sess.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if sess.rank == 0:
+        ms = dt / args.steps * 1e3
+        value = args.steps * args.batch_size * args.gpus / dt
+        out = {
+            'metric': 'images/sec (whole node), CIFAR-10 IWGAN bs=512', 'value': value, 'unit': 'images/sec',
+            'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic (uint8 U{0..255}/255 images, xavier-uniform random-init weights, on-device Philox z/alpha)',
+            'config': {'workload': '--model %s --dataset cifar(32x32x3 synthetic) --batch_size %d/GPU --latent_size %d '
+                                   '--optimizer adam --lr 1e-4 --beta1 0.5 --beta2 0.9 --n_disc_train 5; one step = 5 D + 1 G '
+                                   'optimizer steps on 6 fresh batches' % (args.model, args.batch_size, args.latent_size),
+                       'global_batch': args.batch_size * args.gpus, 'parallelism': 'dp%d' % args.gpus,
+                       'consumed_images_per_sec': value * 6,
+                       'step_tflops': value / args.gpus * GFLOP_PER_IMAGE_ITERATION / 1e3,
+                       'final_losses': status},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            # dominant kernel = the GEMM form/shape with the largest total time in the timed region
+            kind, (n, tot_ms, fl) = max(summ.items(), key=lambda kv: kv[1][1])
+            achieved = fl / (tot_ms * 1e-3) / 1e12
+            gemm_ms = sum(v[1] for v in summ.values())
+            gemm_fl = sum(v[2] for v in summ.values())
+            out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
+                               'frac': achieved / PEAK_TFLOPS[args.dtype], 'traffic': None,
+                               'kernel': kind, 'launches': n, 'avg_launch_ms': tot_ms / n,
+                               'all_conv_gemms': {'ms_per_step': gemm_ms / args.steps,
+                                                  'tflops': gemm_fl / (gemm_ms * 1e-3) / 1e12,
+                                                  'share_of_step': gemm_ms / args.steps / ms},
+                               'per_kernel': {k: {'launches': v[0], 'ms': round(v[1], 3),
+                                                  'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                                              for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

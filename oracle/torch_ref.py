@@ -173,12 +173,12 @@ class TorchGanTrainer:
     def d_step(self, x01, z, alpha):
         _, d_loss = losses(self.P, self.rescale(x01), z, alpha, self.cfg)
         self.d_opt.apply(self.P, grads_of(d_loss, self.P, 'discriminator/'))
-        return float(d_loss)
+        return float(d_loss.detach())
 
     def g_step(self, x01, z, alpha):
         g_loss, d_loss = losses(self.P, self.rescale(x01), z, alpha, self.cfg)
         self.g_opt.apply(self.P, grads_of(g_loss, self.P, 'generator/'))
-        return {'g_loss': float(g_loss), 'd_loss': float(d_loss)}
+        return {'g_loss': float(g_loss.detach()), 'd_loss': float(d_loss.detach())}
 
     def train_func(self, batches, zs, alphas):
         n = self.args.n_disc_train
@@ -188,7 +188,7 @@ class TorchGanTrainer:
             gg = grads_of(g_loss, self.P, 'generator/')
             self.d_opt.apply(self.P, dg)
             self.g_opt.apply(self.P, gg)
-            return {'g_loss': float(g_loss), 'd_loss': float(d_loss)}
+            return {'g_loss': float(g_loss.detach()), 'd_loss': float(d_loss.detach())}
         for i in range(n):
             self.d_step(batches[i], zs[i], alphas[i])
         return self.g_step(batches[n], zs[n], alphas[n])
