@@ -131,6 +131,12 @@ class GanReplica:
         self.d_store.load(arrays)
         self.refresh()
 
+    def stores(self):
+        return [self.g_store, self.d_store]
+
+    def optimizers(self):
+        return {'optimizers/generator': self.g_opt, 'optimizers/discriminator': self.d_opt}
+
     def variables(self):
         d = self.g_store.state_dict()
         d.update(self.d_store.state_dict())

@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Training harness with the command line of the reference's `train.py` (flags :62-182,
+`--config` file action :25-37, options dump :208-213, model dispatch :240-246, epoch/iteration
+loop and checkpoint cadence :279-329) driving the MI355X-native hot path in `3dgan_amd/`.
+
+Differences that are deliberate:
+  * `--data` is accepted as an explicit alias of `--dataset` (README.md:50 relies on prefix matching).
+  * `--n_gpus N` > 1 re-launches this script as N processes (one per GPU, RCCL all-reduce of the
+    gradients) instead of building N in-graph towers; each process is one tower.
+  * TensorFlow's Supervisor/Saver is replaced by `<dir>/checkpoint-<n>.npz` keyed by the reference's
+    variable names; resume-from-`--dir` and `--epochs +n` behave as in train.py:273-282.
+  * There is no CPU fallback (`--n_gpus 0` is an error here; in the reference it is a NameError).
+"""
+import argparse
+import glob
+import importlib
+import os
+import random
+import re
+import subprocess
+import sys
+import time
+import uuid
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class load_args_from_file(argparse.Action):
+    """train.py:25-37: whitespace separated `key value` pairs; '--' is prefixed when missing;
+    values given on the command line win because only truthy parsed values are copied."""
+
+    def __call__(self, parser, namespace, values, option_string=None):
+        contents = [t for line in values.read().splitlines() if not line.strip().startswith('#') for t in line.split()]
+        for i in range(int(len(contents) / 2)):
+            if contents[i * 2][0:2] != '--':
+                contents[i * 2] = '--' + contents[i * 2]
+        data = parser.parse_args(contents, namespace=namespace)
+        for k, v in vars(data).items():
+            if v and k != option_string.strip('-'):
+                setattr(namespace, k, v)
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Autoencoder training harness.',
+                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser._action_groups.pop()
+    model_args = parser.add_argument_group('Model')
+    data_args = parser.add_argument_group('Data')
+    optimizer_args = parser.add_argument_group('Optimizer')
+    train_args = parser.add_argument_group('Training')
+    misc_args = parser.add_argument_group('Miscellaneous')
+    add = misc_args.add_argument
+    add('--config', type=open, action=load_args_from_file,
+        help='Read in a file containing command arguments; command line arguments overwrite it.')
+    add('--seed', type=int, help='Randomized each execution if not set.')
+    add('--n_gpus', type=int, default=1, help='Number of GPUs (one replica process per GPU).')
+    add('--profile', default=False, action='store_true', help='Accepted for compatibility (dead flag in the reference).')
+    add('--check_numerics', default=False, action='store_true', help='Fail with the variable name on NaN/Inf gradients.')
+    add('--precision', default='bf16', choices=['bf16', 'f32'],
+        help='bf16 MFMA with f32 accumulate / master weights (throughput) or exact f32 (parity).')
+    add = train_args.add_argument
+    add('--epochs', default='3', help='Max epochs, or `+n` for n more than the restored checkpoint.')
+    add('--batch_size', type=int, default=256, help='Batch size to use, per device.')
+    add('--epoch_size', type=int, default=-1, help='Iterations per epoch; default: the whole dataset.')
+    add('--examples', type=int, default=64, help='Number of examples to generate when sampling.')
+    add('--dir', type=str, default='workspace/{}'.format(uuid.uuid4()), help='Checkpoints, logs; resumes if populated.')
+    add('--n_disc_train', type=int, default=5, help='Discriminator steps per generator step.')
+    add = optimizer_args.add_argument
+    add('--optimizer', type=lambda s: s.lower(), default='rmsprop')
+    add('--lr', type=float, default=0.001)
+    add('--loss', type=lambda s: s.lower(), default='l1', help='Parsed but unused, as in the reference.')
+    add('--momentum', type=float, default=0.01)
+    add('--decay', type=float, default=0.9)
+    add('--centered', default=False, action='store_true')
+    add('--beta1', type=float, default=0.9)
+    add('--beta2', type=float, default=0.999)
+    add = model_args.add_argument
+    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan (vae, pix2pix: see DESIGN.md).')
+    add('--latent_size', type=int, default=200)
+    add = data_args.add_argument
+    add('--dataset', '--data', dest='dataset', type=lambda s: s.lower(), default='floorplans',
+        help='cifar | mnist | floorplans | synthetic.')
+    add('--resize', type=int, nargs=2, help='Resize input images to w x h.')
+    add('--shuffle', default=True, action='store_true')
+    add('--buffer_size', type=int, default=10000)
+    add('--grayscale', default=False, action='store_true')
+    add('--cache_dir', default=None)
+    add('--data_dir', default='data', help='Where the dataset files live.')
+    return parser
+
+
+def message(s):
+    print('\033[1m\033[92m{}\033[0m'.format(s))
+
+
+def maybe_relaunch(args, argv):
+    """One process per GPU: when asked for several GPUs and not yet under a launcher, start
+    torch.distributed.run as a child (before anything touches the GPU) and exit with its code."""
+    if args.n_gpus <= 1 or 'RANK' in os.environ:
+        return
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(29500 + os.getpid() % 1000), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd))
+
+
+def latest_checkpoint(d):
+    best, best_n = None, -1
+    for f in glob.glob(os.path.join(d, 'checkpoint-*.npz')):
+        m = re.search(r'checkpoint-(\d+)\.npz$', f)
+        if m and int(m.group(1)) > best_n:
+            best, best_n = f, int(m.group(1))
+    return best
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    maybe_relaunch(args, argv)
+    if args.n_gpus < 1:
+        raise SystemExit('--n_gpus 0: this build has no CPU path (the reference raises NameError here, SURVEY App. C-8)')
+
+    import numpy as np
+    import torch
+    from tqdm import tqdm
+    K = importlib.import_module('3dgan_amd.kernels')
+    rt = importlib.import_module('3dgan_amd.runtime')
+    util = importlib.import_module('3dgan_amd.util')
+    datasets = importlib.import_module('3dgan_amd.datasets')
+    ckpt = importlib.import_module('3dgan_amd.checkpoint')
+
+    if args.seed is None:
+        args.seed = int.from_bytes(os.urandom(4), 'little')          # train.py:193-194 (kept an int, App. C-12)
+    random.seed(args.seed)
+    world = rt.init_distributed()
+    sess = rt.Session(dtype=K.BF16 if args.precision == 'bf16' else K.F32, seed=args.seed,
+                      check_numerics=args.check_numerics)
+    chief = sess.rank == 0
+
+    if chief:
+        message('Parsing options...')
+        os.makedirs(args.dir, exist_ok=True)
+        with open(os.path.join(args.dir, 'options.config'), 'w') as f:      # train.py:208-213
+            for a in vars(args):
+                v = getattr(args, a)
+                if a == 'config':
+                    continue
+                f.write('{} {}\n'.format(a, v))
+                print('    {} = {}'.format(a, v))
+
+    if chief:
+        message('Initializing input pipeline...')
+    x, x_count, image_shape = datasets.get_dataset(args, sess)              # train.py:219
+    args.image_shape = image_shape
+    if args.epoch_size <= 0:
+        iter_per_epoch = int(x_count / (args.batch_size * args.n_gpus))     # train.py:222
+    else:
+        iter_per_epoch = args.epoch_size
+
+    if chief:
+        message('Initializing model...')
+    models = importlib.import_module('3dgan_amd.models')
+    model_funcs = models.model_funcs()                                      # train.py:240-244
+    if args.model not in model_funcs:
+        raise SystemExit('unknown --model %r (available: %s)' % (args.model, ', '.join(sorted(model_funcs))))
+    train_func = model_funcs[args.model](x, args, sess)                     # train.py:246
+    replica = train_func.replica
+
+    # resume (tf.train.Supervisor restores the newest checkpoint in --dir, train.py:254-259,273)
+    last = latest_checkpoint(args.dir)
+    if last is not None:
+        ckpt.restore(last, replica, sess)
+        if chief:
+            message('Restored {}'.format(last))
+    for store in replica.stores():
+        rt.broadcast_store(store)
+    replica.refresh()
+
+    start_time = time.time()
+    current_epoch = sess.global_epoch
+    max_epochs = current_epoch + int(args.epochs[1:]) if args.epochs[0] == '+' else int(args.epochs)   # train.py:279-282
+    status = None
+    if sess.global_step == 0 and chief:
+        message('Generating baseline checkpoint...')
+        ckpt.save(os.path.join(args.dir, 'checkpoint-0.npz'), replica, sess)                           # train.py:288-291
+    if chief:
+        message('Starting training...')
+    for epoch in range(current_epoch, max_epochs):
+        it = range(iter_per_epoch)
+        pbar = tqdm(it, desc='Epoch {:3d}'.format(epoch + 1), unit='batch') if chief else it
+        for i in pbar:
+            prev_status = status
+            status = train_func(sess, args)                                                            # train.py:307
+            if chief:
+                pbar.set_postfix(util.format_for_terminal(dict(status), prev_status))
+        sess.global_epoch += 1                                                                         # train.py:322
+        if chief:
+            ckpt.save(os.path.join(args.dir, 'checkpoint-{}.npz'.format(sess.global_epoch)), replica, sess)   # :329
+    if chief:
+        message('\nTraining complete! Elapsed time: {}s'.format(int(time.time() - start_time)))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
