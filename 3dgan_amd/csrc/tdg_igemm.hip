@@ -17,6 +17,8 @@
 //  * Filter gradient: both operands are transposed on the way out of LDS
 //    (ds_read_b64_tr_b16 for bf16, ds_read_b32 for f32), rows split over blockIdx.z into f32
 //    slabs that a second kernel sums in a fixed order (deterministic, no atomics).
+#include <stdlib.h>
+
 #include "tdg_igemm.h"
 
 #define OOB_OFFSET 0xFFFFFF00u
@@ -220,11 +222,13 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
 
   const int nsteps = cl.nsteps;
   load_tiles(0);
+  const int dbg = args.debug;
   for (int step = 0; step < nsteps; ++step) {
-    store_tiles();
+    if (dbg < 2 || step == 0) store_tiles();
     if constexpr (!VECA) gather_scalar(step);
     __syncthreads();
-    if (step + 1 < nsteps) load_tiles(step + 1);
+    if (step + 1 < nsteps && (dbg == 0 || dbg == 3)) load_tiles(step + 1);
+    if (dbg != 3)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int coff = ((ks * 4 + q) ^ swl) << 4;
@@ -294,6 +298,251 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
             if (args.mask_mode != TDG_MASK_NONE) x *= mask_factor(to_f32<T>(msk[pix + n + e]), args.mask_mode, args.leak);
             out[pix + n + e] = from_f32<T>(x);
           }
+        }
+      }
+    }
+  }
+}
+
+// Per-lane walk over the K dimension of the vector gather: K chunk index -> (tap row, tap column,
+// 16-byte vector inside the tap's channels), advanced incrementally (no division, no table lookup,
+// no divergent loop on the common path).
+struct TapWalk {
+  int cv, th, tw;
+  __device__ __forceinline__ void init(int chunk, const FastDiv& fd_cv, int nw) {
+    const int t = (int)fd_div((unsigned)chunk, fd_cv);
+    cv = chunk - t * (int)fd_cv.d;
+    th = t / nw;
+    tw = t - th * nw;
+  }
+  __device__ __forceinline__ void advance(int inc, int CV, int nw) {
+    const int sub = CV >= inc ? inc : 1;            // wave-uniform: one wrap at most per sub-step
+    for (int r = 0; r < inc; r += sub) {
+      cv += sub;
+      const int wrap = cv >= CV;
+      cv -= wrap ? CV : 0;
+      tw += wrap;
+      const int wrap2 = tw >= nw;
+      tw = wrap2 ? 0 : tw;
+      th += wrap2;
+    }
+  }
+};
+
+// ============================================================================================
+// Large-M variant of the forward-type GEMM: 256 x BN tile, 8 waves (one 32-row strip each),
+// operands streamed by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write) into a
+// 2-stage LDS ring, ONE barrier per K step.  LDS-DMA writes lane-linear (base + lane*16), so the
+// bank-conflict swizzle is applied to each lane's SOURCE chunk: a wave instruction fills 8 LDS rows
+// x 8 physical chunks, lane l supplies logical chunk (l&7) ^ ((row>>1)&7).  Instructions are dealt
+// to waves by parity of their index so that this XOR term is one constant per lane.
+// ============================================================================================
+// one K step (2 x 64-byte halves) of a wave's TM x TN tiles, software-pipelined by hand: the B
+// fragment of tile t+2 (and the A fragments of the second half) are requested before the MFMAs of
+// tile t issue, and sched_group_barrier pins that interleave, so an MFMA group never waits for a
+// read issued right in front of it.
+template <typename T, int TM, int TN, int t>
+__device__ __forceinline__ void dma_mma_tile(f32x4 (&acc)[TM][TN], typename Mma<T>::frag (&fa)[2][TM],
+                                             typename Mma<T>::frag (&fb)[2 * TN], const char* pA, const char* pB, int coff0,
+                                             int coff1) {
+  using Frag = typename Mma<T>::frag;
+  constexpr int NT = 2 * TN;
+  if constexpr (t < NT) {
+    constexpr int ks = t / TN, j = t - ks * TN;
+    if constexpr (t + 2 < NT) {
+      constexpr int ks2 = (t + 2) / TN, j2 = (t + 2) - ks2 * TN;
+      fb[t + 2] = *reinterpret_cast<const Frag*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
+    }
+    if constexpr (t < TM) fa[1][t] = *reinterpret_cast<const Frag*>(pA + t * 16 * IG_BKB + coff1);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) Mma<T>::run(acc[i][j], fb[t], fa[ks][i]);
+    __builtin_amdgcn_sched_group_barrier(0x100, (t + 2 < NT ? 1 : 0) + (t < TM ? 1 : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM * (sizeof(T) == 4 ? 4 : 1), 0);
+    dma_mma_tile<T, TM, TN, t + 1>(acc, fa, fb, pA, pB, coff0, coff1);
+  }
+}
+
+template <typename T, int TM, int TN>
+__device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* pA, const char* pB, int q, int swl) {
+  using Frag = typename Mma<T>::frag;
+  const int coff0 = ((0 * 4 + q) ^ swl) << 4, coff1 = ((1 * 4 + q) ^ swl) << 4;
+  Frag fa[2][TM];
+  Frag fb[2 * TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const Frag*>(pA + i * 16 * IG_BKB + coff0);
+  fb[0] = *reinterpret_cast<const Frag*>(pB + coff0);
+  fb[1] = *reinterpret_cast<const Frag*>(pB + 16 * IG_BKB + coff0);
+  __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+  dma_mma_tile<T, TM, TN, 0>(acc, fa, fb, pA, pB, coff0, coff1);
+}
+
+template <typename T, int BN>
+__global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args) {
+  constexpr int BM = 256;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int BKE = IG_BKB / (int)sizeof(T);
+  // waves 4 (M) x 2 (N): 64 rows x 7 or 6 column tiles.  Waves w and w+4 land on the same SIMD
+  // (cyclic placement), so each SIMD carries 13 column tiles in total.
+  constexpr int TM = 4, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
+  constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16; // B rows kept in LDS: both wave columns run TN tiles (the
+                                                    // second one's last tile may spill past BN and is discarded)
+  constexpr int NIB = BNL / 8;                      // B wave-instructions per step (8 rows each)
+  constexpr int NBJ = (NIB + 7) / 8;                // per wave
+  constexpr int STAGE = (BM + BNL) * IG_BKB;
+  static_assert(BN % 16 == 0, "tile config");
+  using Frag = typename Mma<T>::frag;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* sTap = reinterpret_cast<int*>(smem + 2 * STAGE);
+
+  const IgClass& cl = args.cls[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / args.ntiles_n;
+  const int tile_n = bid - tile_m * args.ntiles_n;
+  const int M = cl.M;
+  if (tile_m * BM >= M) return;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int ntaps = cl.ntaps;
+  const int SH = args.SH, SW = args.SW, Cs = args.Cs;
+
+  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
+  const __amdgpu_buffer_rsrc_t rB =
+      make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, args.w_bytes - cl.w_off_bytes);
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int par = wave & 1, wh = wave >> 1;
+  const int rsub = lane >> 3;
+  const int lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
+
+  // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(4*wh + j) + par -------------------
+  int a_h[4], a_w[4];
+  unsigned a_base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * (2 * (4 * wh + j) + par) + rsub;
+    const int m = m0 + row;
+    const bool ok = m < M;
+    const unsigned mm = ok ? (unsigned)m : 0u;
+    const unsigned nb = fd_div(mm, cl.fd_ghw);
+    const unsigned rem = mm - nb * (unsigned)(cl.GH * cl.GW);
+    const unsigned a = fd_div(rem, cl.fd_gw);
+    const unsigned b = rem - a * (unsigned)cl.GW;
+    a_h[j] = ok ? (int)a * args.sigma : -(1 << 20);
+    a_w[j] = (int)b * args.sigma;
+    a_base[j] = ((nb * (unsigned)SH + a * (unsigned)args.sigma) * (unsigned)SW + b * (unsigned)args.sigma) * (unsigned)Cs;
+  }
+  const int CV = (int)args.fd_c.d;
+  const int Kp = cl.Kp, Nn = args.N, nh = cl.nh, nw = cl.nw, dh0 = cl.dh0, dw0 = cl.dw0, shh = cl.sh, sww = cl.sw;
+  TapWalk tw;
+  tw.init(lch, args.fd_c, nw);
+
+  auto issue = [&](int step, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sB = sA + BM * IG_BKB;
+    const int t_ok = tw.th < nh;
+    const int dh = dh0 + shh * tw.th, dw = dw0 + sww * tw.tw;
+    const int koff = (dh * SW + dw) * Cs + tw.cv * VEC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int I = 2 * (4 * wh + j) + par;
+      const int ih = a_h[j] + dh, iw = a_w[j] + dw;
+      const int ok = t_ok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+      const unsigned off = ok ? (a_base[j] + (unsigned)koff) * (unsigned)sizeof(T) : OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(sA + I * 1024), 16, off, 0, 0, 0);
+    }
+    tw.advance(8, CV, nw);
+    const unsigned kb = (unsigned)(step * BKE + lch * VEC);
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int I = 2 * (wh + 4 * j) + par;
+      if (I < NIB) {                                  // wave-uniform
+        const int n = n0 + 8 * I + rsub;
+        const unsigned off = n < Nn ? ((unsigned)n * (unsigned)Kp + kb) * (unsigned)sizeof(T) : OOB_OFFSET;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(sB + I * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  const int r16 = lane & 15, q = lane >> 4;
+  const int swl = (r16 >> 1) & 7;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int tnw = wn == 0 ? TN : TN1;               // wave-uniform
+  static_assert((TN * 16) % 16 == 0 && ((TN * 16) >> 1) % 8 == 0, "swizzle term must not depend on the wave's column base");
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = cl.nsteps;
+  issue(0, 0);
+  __syncthreads();
+  const int dbg = args.debug;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps && (dbg == 0 || dbg == 3)) issue(step + 1, cur ^ 1);
+    const char* pA = smem + cur * STAGE + (wm * 64 + r16) * IG_BKB;
+    const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+    if (dbg != 3)
+    dma_mma_step<T, TM, TN>(acc, pA, pB, q, swl);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane owns pixel r16 x 4 consecutive channels per 16x16 tile; vector path only
+  //      (the launcher guarantees N % 4 == 0 and Cso % 4 == 0) ------------------------------------------
+  const int N = args.N, Cso = args.Cso;
+  T* out = static_cast<T*>(args.out);
+  const T* msk = static_cast<const T*>(args.mask_src);
+  const float* bias = args.bias;
+  const int act = args.act, mmode = args.mask_mode;
+  const float leak = args.leak;
+  size_t pix[TM];
+  bool okm[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + r16;
+    okm[i] = m < M;
+    const unsigned mm = okm[i] ? (unsigned)m : 0u;
+    const unsigned nb = fd_div(mm, cl.fd_ghw);
+    const unsigned rem = mm - nb * (unsigned)(cl.GH * cl.GW);
+    const unsigned a = fd_div(rem, cl.fd_gw);
+    const unsigned b = rem - a * (unsigned)cl.GW;
+    pix[i] = ((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
+              b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)Cso;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + (wn * TN + j) * 16 + q * 4;
+    const bool okn = (j < tnw) && (n < N);
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (okn && bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (okn && okm[i]) {
+        f32x4 v = acc[i][j] + bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, leak);
+        if (mmode != TDG_MASK_NONE) {
+          if constexpr (sizeof(T) == 4) {
+            const f32x4 mv = *reinterpret_cast<const f32x4*>(msk + pix[i] + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mask_factor(mv[e], mmode, leak);
+          } else {
+            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + pix[i] + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= mask_factor((float)mv[e], mmode, leak);
+          }
+        }
+        if constexpr (sizeof(T) == 4) {
+          *reinterpret_cast<f32x4*>(out + pix[i] + n) = v;
+        } else {
+          *reinterpret_cast<bf16x4*>(out + pix[i] + n) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
         }
       }
     }
@@ -635,11 +884,37 @@ int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStre
   return TDG_OK;
 }
 
+template <typename T, int BN>
+int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
+  constexpr int BM = 256;
+  a.ntiles_n = tdg_ceil_div(a.N, BN);
+  a.ntiles_m_max = tdg_ceil_div(mmax, BM);
+  constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
+  const size_t lds = 2 * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BN>), grid, block, lds, s, a);
+  TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
+  return TDG_OK;
+}
+
 template <typename T>
 int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   constexpr int BM = 128;
+  static const int dbg = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+  const char* dma_env = getenv("TDG_DMA");          // diagnostics: 0 = never, 2 = whenever legal, default = by size
+  const int dma_mode = dma_env ? atoi(dma_env) : 1;
+  a.debug = dbg;
   int mmax = 0;
   for (int c = 0; c < a.nclasses; ++c) mmax = a.cls[c].M > mmax ? a.cls[c].M : mmax;
+  // large problems: 256-row tiles fed by LDS-DMA (needs >= ~1 workgroup per CU to pay off)
+  if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0 &&
+      (dma_mode >= 2 || (long long)tdg_ceil_div(mmax, 256) * tdg_ceil_div(a.N, 208) * a.nclasses >= 192))
+    return launch_fwd_dma<T, 208>(a, mmax, s);
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   const int gx = a.ntiles_n * a.ntiles_m_max;
@@ -700,7 +975,7 @@ int validate_desc(const TdgConvDesc* d, const char* who) {
 inline int eff_channels(int c, int cs, int vec) { return (cs % vec == 0 && cs - c < vec) ? cs : 0; }
 
 struct BwdClassPlan {
-  int ntaps;
+  int ntaps, nh, nw;
   int tap_ids[IG_MAX_TAPS];
   int dh[IG_MAX_TAPS], dw[IG_MAX_TAPS];
   int GH, GW, oh0, ow0;
@@ -718,11 +993,14 @@ int plan_bwd_classes(const TdgConvDesc* d, BwdClassPlan* cls) {
       c.ow0 = pw;
       c.GH = (d->h - ph + s - 1) / s;
       c.GW = (d->w - pw + s - 1) / s;
-      c.ntaps = 0;
+      c.ntaps = c.nh = c.nw = 0;
       for (int kh = 0; kh < d->kh; ++kh) {
         if ((ph + d->pad_t - kh) % s != 0) continue;
+        ++c.nh;
+        c.nw = 0;
         for (int kw = 0; kw < d->kw; ++kw) {
           if ((pw + d->pad_l - kw) % s != 0) continue;
+          ++c.nw;
           c.tap_ids[c.ntaps] = kh * d->kw + kw;
           c.dh[c.ntaps] = (ph + d->pad_t - kh) / s;
           c.dw[c.ntaps] = (pw + d->pad_l - kw) / s;
@@ -865,6 +1143,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   c.fd_gw = make_fastdiv(c.GW);
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) c.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
+  c.nh = d->kh; c.nw = d->kw; c.dh0 = -d->pad_t; c.dw0 = -d->pad_l; c.sh = c.sw = 1;
   const int bn = pick_bn(d->k);
   return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
                               : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
@@ -917,6 +1196,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     c.fd_ghw = make_fastdiv(c.GH * c.GW);
     c.fd_gw = make_fastdiv(c.GW);
     for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(plan[i].dh[t], plan[i].dw[t]);
+    c.nh = plan[i].nh; c.nw = plan[i].nw; c.dh0 = plan[i].dh[0]; c.dw0 = plan[i].dw[0]; c.sh = c.sw = -1;
     off += (unsigned)((size_t)d->c * Kp * es);
   }
   const int bn = pick_bn(d->c);

@@ -88,6 +88,16 @@ def test_conv_fwd_bwd(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', [(5, 16, 16, 200, 400, 5, 2), (9, 8, 8, 400, 200, 5, 2), (3, 9, 7, 16, 200, 4, 2)])
+def test_conv_lds_dma_variant(case, dtype, monkeypatch):
+    """The 256-row LDS-DMA tile (normally chosen for large M only) forced on small, ragged problems."""
+    monkeypatch.setenv('TDG_DMA', '2')
+    test_conv_fwd_bwd(case, dtype)
+    monkeypatch.setenv('TDG_DMA', '0')
+    test_conv_fwd_bwd(case, dtype)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
 def test_conv_subbatch_and_classes(dtype):
     """n_images < capacity with a pointer offset (the slot scheme of the D passes)."""
     K = pkg('kernels')
