@@ -53,6 +53,7 @@ SIGNATURES = {
     'tdg_bias_act': (_i, [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp]),
     'tdg_act_bwd': (_i, [_i, _vp, _vp, _sz, _i, _f, _vp, _vp]),
     'tdg_affine_cast': (_i, [_i, _vp, _sz, _f, _f, _vp, _vp]),
+    'tdg_affine_cast_rows': (_i, [_i, _vp, _i, _i, _i, _f, _f, _vp, _vp]),
     'tdg_cast_to_f32': (_i, [_i, _vp, _sz, _vp, _vp]),
     'tdg_cast_from_f32': (_i, [_i, _vp, _sz, _vp, _vp]),
     'tdg_gp_interp': (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp]),

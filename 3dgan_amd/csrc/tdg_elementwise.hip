@@ -501,6 +501,26 @@ extern "C" int tdg_affine_cast(int dtype, const float* in, size_t n, float scale
   TDG_HIP_LAUNCH_CHECK("affine_cast");
   return TDG_OK;
 }
+template <typename T>
+__global__ void __launch_bounds__(256) affine_cast_rows_kernel(const float* __restrict__ in, size_t n, int c, int cs, float scale,
+                                                              float shift, T* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c;
+    const int ch = (int)(i - r * c);
+    out[r * cs + ch] = from_f32<T>(scale * (in[i] + shift));
+  }
+}
+extern "C" int tdg_affine_cast_rows(int dtype, const float* in, int rows, int c, int cs, float scale, float shift, void* out,
+                                    void* stream) {
+  TDG_CHECK_ARG(in && out && rows > 0 && c > 0 && cs >= c, "tdg_affine_cast_rows: bad argument");
+  const size_t n = (size_t)rows * c;
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(affine_cast_rows_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, in, n, c, cs, scale,
+                       shift, static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("affine_cast_rows");
+  return TDG_OK;
+}
 extern "C" int tdg_cast_from_f32(int dtype, const float* in, size_t n, void* out, void* stream) {
   return tdg_affine_cast(dtype, in, n, 1.f, 0.f, out, stream);
 }

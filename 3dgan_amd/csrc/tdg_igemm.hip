@@ -972,7 +972,7 @@ int validate_desc(const TdgConvDesc* d, const char* who) {
 }
 
 // effective channel count of a tensor side for the vector gather (0 -> scalar path)
-inline int eff_channels(int c, int cs, int vec) { return (cs % vec == 0 && cs - c < vec) ? cs : 0; }
+inline int eff_channels(int c, int cs, int vec) { (void)c; return cs % vec == 0 ? cs : 0; }
 
 struct BwdClassPlan {
   int ntaps, nh, nw;

@@ -27,9 +27,10 @@ def ptr(t, byte_offset=0):
 
 
 def pad_channels(c, multiple=8):
-    """Channel stride of an activation buffer: multiples of 8 keep 16-byte gathers legal in
-    both dtypes; thin tensors (images, c <= 4) stay compact and take the scalar gather."""
-    return c if c <= 4 else (c + multiple - 1) // multiple * multiple
+    """Channel stride of an activation buffer: a multiple of 8 keeps the 16-byte vector gather
+    legal in both dtypes.  Images (c = 1, 3, 4) are padded to 8 channels too: the extra MFMA work
+    on zero channels is far cheaper than the element-wise gather a compact layout would need."""
+    return (c + multiple - 1) // multiple * multiple
 
 
 class Act:

@@ -79,7 +79,7 @@ class GanReplica:
         B, L = args.batch_size, args.latent_size
         h, w, c = args.image_shape
         dev, dt = sess.device, sess.dtype
-        self.B, self.img_elems = B, h * w * c
+        self.B = B
         self.iwgan = self.model == 'iwgan'
         self.display_d_loss = getattr(args, 'display_d_loss', True)
         if self.model == 'gan':
@@ -117,6 +117,7 @@ class GanReplica:
         self.G.init_variables(gen)
         self.D.init_variables(gen)
         self.g_opt, self.d_opt = init_optimizer(args, self.g_store), init_optimizer(args, self.d_store)   # :46
+        self.img_elems = self.D.x.image_elems        # channel-padded image size in HBM
         self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float32, device=dev)
         self.refresh()
@@ -150,10 +151,12 @@ class GanReplica:
     # -- pieces ------------------------------------------------------------------------------------
     def _load_real(self, x01):
         """models/gan.py:49-50: x = 2 * (flatten(x) - 0.5) into slot 0."""
-        n = self.B * self.img_elems
+        h, w, c = self.args.image_shape
+        n = self.B * h * w * c
         if x01.dtype != torch.float32 or x01.numel() != n:
             raise ValueError('expected a float32 batch of %d values in [0,1], got %s %s' % (n, x01.dtype, tuple(x01.shape)))
-        _lib.call('tdg_affine_cast', self.sess.dtype, K.ptr(x01.contiguous()), n, 2.0, -0.5, self.D.x.ptr(0), K.stream())
+        _lib.call('tdg_affine_cast_rows', self.sess.dtype, K.ptr(x01.contiguous()), self.B * h * w, c, self.D.x.cs, 2.0, -0.5,
+                  self.D.x.ptr(0), K.stream())
 
     def _generate(self):
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246

@@ -138,6 +138,9 @@ int tdg_act_bwd(int dtype, const void* dy, const void* post, size_t n, int act, 
                 void* stream);
 /* out = scale * (in + shift), f32 in -> dtype out   (models/gan.py:50: 2*(x-0.5)) */
 int tdg_affine_cast(int dtype, const float* in, size_t n, float scale, float shift, void* out, void* stream);
+/* out[r*cs + ch] = scale * (in[r*c + ch] + shift), ch < c: compact f32 rows -> channel-padded activation */
+int tdg_affine_cast_rows(int dtype, const float* in, int rows, int c, int cs, float scale, float shift, void* out,
+                         void* stream);
 int tdg_cast_to_f32(int dtype, const void* in, size_t n, float* out, void* stream);
 int tdg_cast_from_f32(int dtype, const float* in, size_t n, void* out, void* stream);
 /* xhat[r,:] = x[r,:] + alpha[r] * (g[r,:] - x[r,:])   (models/gan.py:225-226) */

@@ -39,10 +39,10 @@ CONV_CASES = [
 ]
 
 
-def make_conv(K, dtype, n, h, w, cin, cout, k, s, dev):
+def make_conv(K, dtype, n, h, w, cin, cout, k, s, dev, compact=False):
     oh, pt, _ = T.same_pad(h, k, s)
     ow, pl, _ = T.same_pad(w, k, s)
-    big = K.Act(n, h, w, cin, dtype, dev)
+    big = K.Act(n, h, w, cin, dtype, dev, cs=(cin if compact else None))
     small = K.Act(n, oh, ow, cout, dtype, dev)
     conv = K.Conv(big, small, k, k, s, pt, pl)
     return big, small, conv
@@ -95,6 +95,32 @@ def test_conv_lds_dma_variant(case, dtype, monkeypatch):
     test_conv_fwd_bwd(case, dtype)
     monkeypatch.setenv('TDG_DMA', '0')
     test_conv_fwd_bwd(case, dtype)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+def test_conv_compact_thin_input_takes_the_scalar_gather(dtype):
+    """A caller-provided compact layout (channel stride 3) cannot use 16-byte gathers."""
+    K = pkg('kernels')
+    dev = torch.device('cuda:0')
+    n, h, w, cin, cout, k, s = 3, 16, 16, 3, 24, 5, 2
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / 8).astype(np.float32)
+    if dtype == 1:
+        x, Wt = bf16_round(x), bf16_round(Wt)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev, compact=True)
+    assert big.cs == 3
+    conv.pack(torch.tensor(Wt, device=dev))
+    big.set(x)
+    conv.fwd(big.ptr(), small.ptr(), n)
+    assert relerr(small.get(), T.conv2d(x.astype(np.float64), Wt.astype(np.float64), s)) < TOL[dtype]
+    dy = rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32)
+    if dtype == 1:
+        dy = bf16_round(dy)
+    small.set(dy)
+    dw = torch.zeros(k, k, cin, cout, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n)
+    assert relerr(dw.cpu().numpy(), T.conv2d_backprop_filter(x.astype(np.float64), Wt.shape, dy.astype(np.float64), s)) < TOL[dtype]
 
 
 @pytest.mark.parametrize('dtype', [0, 1])
