@@ -35,6 +35,7 @@ _PD, _PE = C.POINTER(ConvDesc), C.POINTER(Epilogue)
 SIGNATURES = {
     'tdg_last_error': (C.c_char_p, []),
     'tdg_version': (_i, []),
+    'tdg_last_kernel': (C.c_char_p, []),
     'tdg_packed_filter_fwd_bytes': (_sz, [_PD]),
     'tdg_packed_filter_bwd_bytes': (_sz, [_PD]),
     'tdg_pack_filter_fwd': (_i, [_PD, _vp, _vp, _vp]),
@@ -65,12 +66,16 @@ SIGNATURES = {
     'tdg_fill_f32': (_i, [_vp, _sz, _f, _vp]),
     'tdg_bias_grad': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp, _sz, _vp]),
     'tdg_adam_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
+    'tdg_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
+    'tdg_add_i32': (_i, [_vp, _i, _vp]),
     'tdg_rmsprop_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
     'tdg_sgd_momentum_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     'tdg_clamp': (_i, [_vp, _sz, _f, _f, _vp]),
     'tdg_check_finite': (_i, [_vp, _sz, _vp, _vp]),
     'tdg_random_normal': (_i, [_i, _u64, _u64, _u64, _sz, _vp, _vp]),
     'tdg_random_uniform_f32': (_i, [_u64, _u64, _u64, _sz, _vp, _vp]),
+    'tdg_random_normal_dev': (_i, [_i, _u64, _u64, _vp, _sz, _vp, _vp]),
+    'tdg_random_uniform_f32_dev': (_i, [_u64, _u64, _vp, _sz, _vp, _vp]),
 }
 
 _lib = None

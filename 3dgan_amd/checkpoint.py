@@ -28,7 +28,7 @@ def restore(path, replica, sess):
     for name, opt in replica.optimizers().items():
         if opt is None or '%s/t' % name not in z:
             continue
-        opt.t = int(z['%s/t' % name])
+        opt.set_step_count(int(z['%s/t' % name]))
         for slot, t in opt.state_tensors().items():
             t.copy_(torch.as_tensor(z['%s/%s' % (name, slot)]))
     sess.global_step = int(z['global_step'])

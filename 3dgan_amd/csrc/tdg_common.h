@@ -18,6 +18,7 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 
 // ---------------------------------------------------------------------------- errors
 void tdg_set_error(const char* fmt, ...);
+void tdg_note_kernel(const char* name);
 
 #define TDG_CHECK_ARG(cond, ...)   \
   do {                             \

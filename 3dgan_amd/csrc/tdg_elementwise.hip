@@ -16,6 +16,9 @@ void tdg_set_error(const char* fmt, ...) {
 }
 extern "C" const char* tdg_last_error(void) { return g_err; }
 extern "C" int tdg_version(void) { return 100; }
+static thread_local const char* g_last_kernel = "";
+void tdg_note_kernel(const char* name) { g_last_kernel = name; }
+extern "C" const char* tdg_last_kernel(void) { return g_last_kernel; }
 
 #define DISPATCH_T(dtype, ...)                  \
   if ((dtype) == TDG_BF16) {                    \
@@ -670,6 +673,39 @@ extern "C" int tdg_adam_step(float* p, const float* g, float* m, float* v, size_
   return TDG_OK;
 }
 
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
+                                                      float gs, const int* __restrict__ t_dev) {
+  const float t = (float)(t_dev[0] + 1);
+  const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+    mv = b1 * mv + (1.f - b1) * gv;
+    vv = b2 * vv + (1.f - b2) * gv * gv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[e] -= lr_t * mv[e] / (sqrtf(vv[e]) + eps);
+    reinterpret_cast<f32x4*>(m)[i] = mv;
+    reinterpret_cast<f32x4*>(v)[i] = vv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                                 float eps, float grad_scale, const int32_t* t_dev, void* stream) {
+  TDG_CHECK_ARG(p && g && m && v && t_dev && n > 0 && (n & 3) == 0, "tdg_adam_step_dev: bad argument (n must be a multiple of 4)");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
+                     beta1, beta2, eps, grad_scale, t_dev);
+  TDG_HIP_LAUNCH_CHECK("adam_dev");
+  return TDG_OK;
+}
+__global__ void add_i32_kernel(int* x, int inc) { x[0] += inc; }
+extern "C" int tdg_add_i32(int32_t* x, int32_t inc, void* stream) {
+  TDG_CHECK_ARG(x, "tdg_add_i32: null pointer");
+  hipLaunchKernelGGL(add_i32_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, x, inc);
+  TDG_HIP_LAUNCH_CHECK("add_i32");
+  return TDG_OK;
+}
+
 __global__ void __launch_bounds__(256) rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ rms,
                                                      float* __restrict__ mom, size_t n4, float lr, float decay, float mu,
                                                      float eps, float gs) {
@@ -755,7 +791,9 @@ struct Philox {
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1)
 
 template <typename T>
-__global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint64_t sid, uint64_t offset, size_t n, T* __restrict__ out) {
+__global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint64_t sid, uint64_t offset, const int* __restrict__ draw_dev,
+                                                           size_t n, T* __restrict__ out) {
+  if (draw_dev) offset = ((uint64_t)(unsigned)(draw_dev[0] + 1)) << 24;
   const size_t n4 = (n + 3) >> 2;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     Philox ph;
@@ -779,14 +817,25 @@ extern "C" int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, u
   TDG_CHECK_ARG(out && n > 0, "tdg_random_normal: bad argument");
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(random_normal_kernel<T>, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                       stream_id, offset, n, static_cast<T*>(out));
+                       stream_id, offset, (const int*)nullptr, n, static_cast<T*>(out));
   })
   TDG_HIP_LAUNCH_CHECK("random_normal");
   return TDG_OK;
 }
+extern "C" int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, void* out,
+                                     void* stream) {
+  TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_normal_dev: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(random_normal_kernel<T>, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       stream_id, (uint64_t)0, draw_dev, n, static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("random_normal_dev");
+  return TDG_OK;
+}
 
-__global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint64_t sid, uint64_t offset, size_t n,
-                                                            float* __restrict__ out) {
+__global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint64_t sid, uint64_t offset,
+                                                            const int* __restrict__ draw_dev, size_t n, float* __restrict__ out) {
+  if (draw_dev) offset = ((uint64_t)(unsigned)(draw_dev[0] + 1)) << 24;
   const size_t n4 = (n + 3) >> 2;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     Philox ph;
@@ -799,7 +848,15 @@ __global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint
 extern "C" int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out, void* stream) {
   TDG_CHECK_ARG(out && n > 0, "tdg_random_uniform_f32: bad argument");
   hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                     stream_id, offset, n, out);
+                     stream_id, offset, (const int*)nullptr, n, out);
   TDG_HIP_LAUNCH_CHECK("random_uniform");
+  return TDG_OK;
+}
+extern "C" int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, float* out,
+                                          void* stream) {
+  TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_uniform_f32_dev: bad argument");
+  hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                     stream_id, (uint64_t)0, draw_dev, n, out);
+  TDG_HIP_LAUNCH_CHECK("random_uniform_dev");
   return TDG_OK;
 }

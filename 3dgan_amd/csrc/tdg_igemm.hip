@@ -880,6 +880,11 @@ int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStre
     hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, true>), grid, block, lds, s, a);
   else
     hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, false>), grid, block, lds, s, a);
+  {
+    static const char* names[2][4] = {{"igemm_fwd_kernel<f32,128,16>", "igemm_fwd_kernel<f32,128,64>", "igemm_fwd_kernel<f32,128,128>", "igemm_fwd_kernel<f32,128,208>"},
+                                      {"igemm_fwd_kernel<bf16,128,16>", "igemm_fwd_kernel<bf16,128,64>", "igemm_fwd_kernel<bf16,128,128>", "igemm_fwd_kernel<bf16,128,208>"}};
+    tdg_note_kernel(names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
+  }
   TDG_HIP_LAUNCH_CHECK("igemm_fwd");
   return TDG_OK;
 }
@@ -898,6 +903,7 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
   }
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
   hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BN>), grid, block, lds, s, a);
+  tdg_note_kernel(sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,208>" : "igemm_fwd_dma_kernel<f32,208>");
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
 }
@@ -937,6 +943,11 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
     hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, true>), grid, block, lds, s, a);
   else
     hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, false>), grid, block, lds, s, a);
+  {
+    static const char* names[2][4] = {{"igemm_wgrad_kernel<f32,128,16>", "igemm_wgrad_kernel<f32,128,64>", "igemm_wgrad_kernel<f32,128,128>", "igemm_wgrad_kernel<f32,128,208>"},
+                                      {"igemm_wgrad_kernel<bf16,128,16>", "igemm_wgrad_kernel<bf16,128,64>", "igemm_wgrad_kernel<bf16,128,128>", "igemm_wgrad_kernel<bf16,128,208>"}};
+    tdg_note_kernel(names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
+  }
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad");
   return TDG_OK;
 }

@@ -93,6 +93,9 @@ class Optimizer:
     def _slot(self, fill=0.0):
         return torch.full_like(self.store.params, fill)
 
+    def set_step_count(self, t):
+        self.t = int(t)
+
     def state_tensors(self):
         return {}
 
@@ -102,13 +105,26 @@ class Adam(Optimizer):
         super().__init__(store)
         self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
         self.m, self.v = self._slot(), self._slot()
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=store.device)    # step count for graph replay
+
+    @property
+    def t(self):
+        return int(self.t_dev.item())             # the device counter is authoritative (graph replays bump only it)
+
+    @t.setter
+    def t(self, value):
+        if hasattr(self, 't_dev'):
+            self.t_dev.fill_(int(value))
 
     def step(self, grad_scale=1.0):
-        self.t += 1
-        lr_t = self.lr * math.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        """lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is derived in-kernel from the device-resident step count."""
         s = self.store
-        _lib.call('tdg_adam_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.m), K.ptr(self.v), s.size,
-                  lr_t, self.b1, self.b2, self.eps, grad_scale, K.stream())
+        _lib.call('tdg_adam_step_dev', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.m), K.ptr(self.v), s.size,
+                  self.lr, self.b1, self.b2, self.eps, grad_scale, K.ptr(self.t_dev), K.stream())
+        _lib.call('tdg_add_i32', K.ptr(self.t_dev), 1, K.stream())
+
+    def set_step_count(self, t):
+        self.t_dev.fill_(int(t))
 
     def state_tensors(self):
         return {'m': self.m, 'v': self.v}

@@ -101,14 +101,17 @@ class GemmTimer:
         a.record()
         fn()
         b.record()
-        self.records.append((kind, a, b, flops))
+        symbol = _lib.load().tdg_last_kernel().decode()          # the kernel variant the library dispatched to
+        self.records.append((kind, a, b, flops, symbol))
 
-    def summary(self):
-        """{kind: (launches, total_ms, total_flops)} -- call after a synchronize."""
+    def summary(self, by_symbol=False):
+        """{kind or kernel symbol: (launches, total_ms, total_flops)} -- call after a synchronize.
+        (bwd_filter timings include the slab_reduce launch that follows the GEMM.)"""
         out = {}
-        for kind, a, b, fl in self.records:
-            n, ms, f = out.get(kind, (0, 0.0, 0.0))
-            out[kind] = (n + 1, ms + a.elapsed_time(b), f + fl)
+        for kind, a, b, fl, symbol in self.records:
+            key = symbol if by_symbol else kind
+            n, ms, f = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, ms + a.elapsed_time(b), f + fl)
         return out
 
 

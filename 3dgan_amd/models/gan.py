@@ -118,6 +118,11 @@ class GanReplica:
         self.D.init_variables(gen)
         self.g_opt, self.d_opt = init_optimizer(args, self.g_store), init_optimizer(args, self.d_store)   # :46
         self.img_elems = self.D.x.image_elems        # channel-padded image size in HBM
+        # hipGraph replay of the two step bodies (launch-bound otherwise: ~600 small launches per iteration)
+        self.use_graphs = bool(getattr(args, 'use_graphs', True)) and dev.type == 'cuda' and not sess.check_numerics
+        self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
+        self._graphs = {}
+        self._warm = set()
         self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float32, device=dev)
         self.refresh()
@@ -155,8 +160,32 @@ class GanReplica:
         n = self.B * h * w * c
         if x01.dtype != torch.float32 or x01.numel() != n:
             raise ValueError('expected a float32 batch of %d values in [0,1], got %s %s' % (n, x01.dtype, tuple(x01.shape)))
-        _lib.call('tdg_affine_cast_rows', self.sess.dtype, K.ptr(x01.contiguous()), self.B * h * w, c, self.D.x.cs, 2.0, -0.5,
+        self.x_stage.copy_(x01.reshape(self.x_stage.shape))          # fixed address: the step bodies may be graph-captured
+
+
+    def _rescale_real(self):
+        h, w, c = self.args.image_shape
+        _lib.call('tdg_affine_cast_rows', self.sess.dtype, K.ptr(self.x_stage), self.B * h * w, c, self.D.x.cs, 2.0, -0.5,
                   self.D.x.ptr(0), K.stream())
+
+    def _run(self, name, body):
+        """Run a step body eagerly the first time (lazy workspaces, kernel attributes), capture it into a
+        hipGraph the second time and replay it afterwards.  All step-varying inputs (batch, RNG draw
+        counter, Adam step count) live at fixed device addresses, so a replay is a new step."""
+        if not self.use_graphs or self.sess.inject:
+            return body()
+        g = self._graphs.get(name)
+        if g is not None:
+            return g.replay()
+        if name not in self._warm:
+            self._warm.add(name)
+            return body()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        self._graphs[name] = g
+        g.replay()
 
     def _generate(self):
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246
@@ -196,8 +225,25 @@ class GanReplica:
     # -- steps -------------------------------------------------------------------------------------
     def d_step(self, x01):
         """One run of d_train_op (models/gan.py:152,171): d_loss gradients w.r.t. D, averaged, applied."""
-        B, R = self.B, self.B * self.rows_per_image
         self._load_real(x01)
+        self._run('d_grads', self._d_grads)
+        self.sess.assert_finite(self.d_store, 'd_step')
+        scale = average_gradients(self.sess, self.d_store)            # models/gan.py:77 (RCCL, outside the graphs)
+        self._scale = scale
+        self._run('d_apply', self._d_apply)
+        self.sess.global_step += 1
+
+    def _d_apply(self):
+        self.d_opt.step(self._scale)                                  # models/gan.py:81
+        self.D.repack()
+
+    def _g_apply(self):
+        self.g_opt.step(self._scale)                                  # models/gan.py:80
+        self.G.repack()
+
+    def _d_grads(self):
+        B, R = self.B, self.B * self.rows_per_image
+        self._rescale_real()
         self._generate()
         if self.iwgan:
             self._interpolate()
@@ -216,18 +262,22 @@ class GanReplica:
         else:
             self.D.backward(0, B, bn_pass=0, want_params=True, acc=False)
             self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
-        self.sess.assert_finite(self.d_store, 'd_step')
-        scale = average_gradients(self.sess, self.d_store)            # models/gan.py:77
-        self.d_opt.step(scale)                                        # :81
-        self.sess.global_step += 1
-        self.D.repack()
 
     def g_step(self, x01):
         """One run of [g_train_op, losses] (models/gan.py:153,172)."""
+        if self.display_d_loss:
+            self._load_real(x01)
+        self._run('g_grads', self._g_grads)
+        self.sess.assert_finite(self.g_store, 'g_step')
+        self._scale = average_gradients(self.sess, self.g_store)      # models/gan.py:76
+        self._run('g_apply', self._g_apply)
+        self.sess.global_step += 1
+
+    def _g_grads(self):
         B, R = self.B, self.B * self.rows_per_image
         self._generate()
         if self.display_d_loss:
-            self._load_real(x01)
+            self._rescale_real()
             if self.iwgan:
                 self._interpolate()
             scores = self._d_forward(0, self.nslots)
@@ -242,11 +292,6 @@ class GanReplica:
         else:
             self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
         self.G.backward(0, B, want_params=True)                       # seed = D.dx slot 1 (aliased)
-        self.sess.assert_finite(self.g_store, 'g_step')
-        scale = average_gradients(self.sess, self.g_store)            # models/gan.py:76
-        self.g_opt.step(scale)                                        # :80
-        self.sess.global_step += 1
-        self.G.repack()
 
     def losses(self):
         """Host read-back of the device scalars (one sync): models/gan.py:196-205."""

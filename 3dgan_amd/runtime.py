@@ -37,13 +37,15 @@ class Session:
         self.global_step = 0                         # train.py:201 (bumped by BOTH apply ops, gan.py:79-81)
         self.global_epoch = 0                        # train.py:202
         self._draws = 0
+        self._draws_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # same count, device resident
         self.inject = {}                             # tests: {'z': [..], 'alpha': [..]} consumed in order
         self._flag = None
 
     # ---- RNG (tf.random_normal / tf.random_uniform, models/gan.py:246,224) ---------
-    def _next_offset(self):
+    def _bump_draws(self):
+        """The draw counter lives in device memory so that a captured hipGraph replays fresh streams."""
         self._draws += 1
-        return self._draws << 24
+        _lib.call('tdg_add_i32', K.ptr(self._draws_dev), 1, K.stream())
 
     def _injected(self, key):
         q = self.inject.get(key)
@@ -59,15 +61,18 @@ class Session:
             t = torch.as_tensor(inj, dtype=torch.float32).reshape(-1)
             act.buf[:n].copy_(t.to(self.device, K.TORCH_DTYPE[act.dtype]))
             return
-        _lib.call('tdg_random_normal', act.dtype, self.seed, (self.rank << 8) | 1, self._next_offset(), n,
+        _lib.call('tdg_random_normal_dev', act.dtype, self.seed, (self.rank << 8) | 1, K.ptr(self._draws_dev), n,
                   act.ptr(0), K.stream())
+        self._bump_draws()
 
     def random_uniform(self, out, n, key='alpha'):
         inj = self._injected(key)
         if inj is not None:
             out[:n].copy_(torch.as_tensor(inj, dtype=torch.float32).reshape(-1).to(self.device))
             return
-        _lib.call('tdg_random_uniform_f32', self.seed, (self.rank << 8) | 2, self._next_offset(), n, K.ptr(out), K.stream())
+        _lib.call('tdg_random_uniform_f32_dev', self.seed, (self.rank << 8) | 2, K.ptr(self._draws_dev), n, K.ptr(out),
+                  K.stream())
+        self._bump_draws()
 
     # ---- gradient exchange (util.py:118-147 average_gradients) ---------------------------------------
     def allreduce_mean_scale(self, flat_grads):

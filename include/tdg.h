@@ -74,6 +74,9 @@ typedef struct TdgEpilogue {
 
 const char* tdg_last_error(void);
 int tdg_version(void);
+/* Name of the GEMM kernel variant chosen by this thread's most recent tdg_conv2d_* call (profiling aid:
+ * lets a caller attribute HIP-event timings to the kernel symbols rocprofv3 reports). */
+const char* tdg_last_kernel(void);
 
 /* ---- filter packing: f32 master -> GEMM operand layout in desc.dtype ------------------
  * FWD form  : rows = k (small-side channels), K = (tap, c)        -> used by tdg_conv2d_fwd
@@ -167,6 +170,12 @@ int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs, float* db,
 /* Adam: lr_t = lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller */
 int tdg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
+/* Same update with the step count t kept in device memory (t_dev[0] = number of steps already applied):
+ * lr_t is derived in-kernel, so a captured hipGraph can be replayed without re-baking arguments.
+ * Follow with tdg_add_i32(t_dev, 1). */
+int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                      float beta2, float eps, float grad_scale, const int32_t* t_dev, void* stream);
+int tdg_add_i32(int32_t* x, int32_t inc, void* stream);
 /* RMSProp (rms slot initialised to 1 by the caller), optional momentum, not centered */
 int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom, size_t n, float lr,
                      float decay, float momentum, float eps, float grad_scale, void* stream);
@@ -183,6 +192,12 @@ int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t off
                       void* out, void* stream);
 int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out,
                            void* stream);
+/* Graph-replayable forms: the counter offset is (draw_dev[0] << 24), read from device memory;
+ * follow each draw with tdg_add_i32(draw_dev, 1). */
+int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n,
+                          void* out, void* stream);
+int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, float* out,
+                               void* stream);
 
 #ifdef __cplusplus
 }

@@ -139,7 +139,7 @@ def test_param_store_checkpoint_round_trip(tmp_path):
     assert s.index['generator/vars/fc1/bias'][0] % 4 == 0 and s.size % 4 == 0
     s['generator/vars/fc1/weights'].copy_(torch.arange(15.).view(3, 5))
     opt = eng.Optimizer(s)
-    opt.t = 7
+    opt.set_step_count(7)
     rep = SimpleNamespace(stores=lambda: [s], optimizers=lambda: {'optimizers/generator': opt})
     sess = SimpleNamespace(global_step=12, global_epoch=2)
     path = str(tmp_path / 'checkpoint-2.npz')
