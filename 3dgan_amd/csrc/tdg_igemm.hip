@@ -376,14 +376,16 @@ __device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* p
   dma_mma_tile<T, TM, TN, 0>(acc, fa, fb, pA, pB, coff0, coff1);
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args) {
-  constexpr int BM = 256;
+  static_assert(BM % 64 == 0, "4 wave rows of BM/4 = k*16 rows, 8-row DMA instructions dealt in pairs");
+  constexpr int NAJ = BM / 64;                      // A wave-instructions per wave per step
+  constexpr int WMR = BM / 4;                       // rows per wave row
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int BKE = IG_BKB / (int)sizeof(T);
   // waves 4 (M) x 2 (N): 64 rows x 7 or 6 column tiles.  Waves w and w+4 land on the same SIMD
   // (cyclic placement), so each SIMD carries 13 column tiles in total.
-  constexpr int TM = 4, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
+  constexpr int TM = WMR / 16, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16; // B rows kept in LDS: both wave columns run TN tiles (the
                                                     // second one's last tile may spill past BN and is discarded)
   constexpr int NIB = BNL / 8;                      // B wave-instructions per step (8 rows each)
@@ -420,11 +422,11 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   const int lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
 
   // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(4*wh + j) + par -------------------
-  int a_h[4], a_w[4];
-  unsigned a_base[4];
+  int a_h[NAJ], a_w[NAJ];
+  unsigned a_base[NAJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 8 * (2 * (4 * wh + j) + par) + rsub;
+  for (int j = 0; j < NAJ; ++j) {
+    const int row = 8 * (2 * (NAJ * wh + j) + par) + rsub;
     const int m = m0 + row;
     const bool ok = m < M;
     const unsigned mm = ok ? (unsigned)m : 0u;
@@ -448,8 +450,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     const int dh = dh0 + shh * tw.th, dw = dw0 + sww * tw.tw;
     const int koff = (dh * SW + dw) * Cs + tw.cv * VEC;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int I = 2 * (4 * wh + j) + par;
+    for (int j = 0; j < NAJ; ++j) {
+      const int I = 2 * (NAJ * wh + j) + par;
       const int ih = a_h[j] + dh, iw = a_w[j] + dw;
       const int ok = t_ok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
       const unsigned off = ok ? (a_base[j] + (unsigned)koff) * (unsigned)sizeof(T) : OOB_OFFSET;
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
     if (step + 1 < nsteps && (dbg == 0 || dbg == 3)) issue(step + 1, cur ^ 1);
-    const char* pA = smem + cur * STAGE + (wm * 64 + r16) * IG_BKB;
+    const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
     const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
     if (dbg != 3)
     dma_mma_step<T, TM, TN>(acc, pA, pB, q, swl);
@@ -506,7 +508,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   bool okm[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + r16;
+    const int m = m0 + wm * WMR + i * 16 + r16;
     okm[i] = m < M;
     const unsigned mm = okm[i] ? (unsigned)m : 0u;
     const unsigned nb = fd_div(mm, cl.fd_ghw);
@@ -883,27 +885,28 @@ int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStre
   {
     static const char* names[2][4] = {{"igemm_fwd_kernel<f32,128,16>", "igemm_fwd_kernel<f32,128,64>", "igemm_fwd_kernel<f32,128,128>", "igemm_fwd_kernel<f32,128,208>"},
                                       {"igemm_fwd_kernel<bf16,128,16>", "igemm_fwd_kernel<bf16,128,64>", "igemm_fwd_kernel<bf16,128,128>", "igemm_fwd_kernel<bf16,128,208>"}};
-    tdg_note_kernel(names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
+    tdg_note_kernel(BM == 64 ? (sizeof(T) == 2 ? "igemm_fwd_kernel<bf16,64,208>" : "igemm_fwd_kernel<f32,64,208>")
+                             : names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
   }
   TDG_HIP_LAUNCH_CHECK("igemm_fwd");
   return TDG_OK;
 }
 
-template <typename T, int BN>
+template <typename T, int BM, int BN>
 int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
-  constexpr int BM = 256;
   a.ntiles_n = tdg_ceil_div(a.N, BN);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
   const size_t lds = 2 * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
-  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BN>), grid, block, lds, s, a);
-  tdg_note_kernel(sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,208>" : "igemm_fwd_dma_kernel<f32,208>");
+  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN>), grid, block, lds, s, a);
+  tdg_note_kernel(BM == 256 ? (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,256,208>" : "igemm_fwd_dma_kernel<f32,256,208>")
+                            : (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,192,208>" : "igemm_fwd_dma_kernel<f32,192,208>"));
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
 }
@@ -919,11 +922,23 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   for (int c = 0; c < a.nclasses; ++c) mmax = a.cls[c].M > mmax ? a.cls[c].M : mmax;
   // large problems: 256-row tiles fed by LDS-DMA (needs >= ~1 workgroup per CU to pay off)
   if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0 &&
-      (dma_mode >= 2 || (long long)tdg_ceil_div(mmax, 256) * tdg_ceil_div(a.N, 208) * a.nclasses >= 192))
-    return launch_fwd_dma<T, 208>(a, mmax, s);
+      (dma_mode >= 2 || (long long)tdg_ceil_div(mmax, 256) * tdg_ceil_div(a.N, 208) * a.nclasses >= 192)) {
+    // one 8-wave workgroup per CU: pick the row tile whose workgroup count wastes less of the last round
+    const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
+    const long long t256 = per * tdg_ceil_div(mmax, 256), t192 = per * tdg_ceil_div(mmax, 192);
+    const double e256 = (double)t256 / (tdg_ceil_div(t256, 256) * 256.0), e192 = (double)t192 / (tdg_ceil_div(t192, 256) * 256.0);
+    if (dma_mode == 3 || (dma_mode != 4 && e192 > e256 + 0.08)) return launch_fwd_dma<T, 192, 208>(a, mmax, s);
+    return launch_fwd_dma<T, 256, 208>(a, mmax, s);
+  }
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
-  const int gx = a.ntiles_n * a.ntiles_m_max;
+  int gx = a.ntiles_n * a.ntiles_m_max;
+  // under-filled chip (fewer than ~1.5 workgroups per CU): halve the row tile to double the grid
+  if (bn == 208 && (long long)gx * a.nclasses < 384) {
+    a.ntiles_m_max = tdg_ceil_div(mmax, 64);
+    gx = a.ntiles_n * a.ntiles_m_max;
+    return launch_fwd_cfg<T, 64, 208, 4, 1>(a, veca, gx, a.nclasses, s);
+  }
   switch (bn) {
     case 16: return launch_fwd_cfg<T, BM, 16, 4, 1>(a, veca, gx, a.nclasses, s);
     case 64: return launch_fwd_cfg<T, BM, 64, 4, 1>(a, veca, gx, a.nclasses, s);
@@ -1222,7 +1237,7 @@ static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   if (!ce) ce = d->c;
   const int M = n_images * d->oh * d->ow;
   const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, 128) * tdg_ceil_div(d->k, pick_bn(d->k));
-  int want = tdg_ceil_div(1024, tiles);                 // aim for >= ~4 workgroups per CU
+  int want = tdg_ceil_div(768, tiles);                  // aim for ~3 workgroups per CU
   const int max_split = tdg_ceil_div(M, mr * 4);        // keep >= 4 steps per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
