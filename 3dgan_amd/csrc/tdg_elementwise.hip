@@ -608,6 +608,33 @@ extern "C" int tdg_mean_f32(const float* x, int n, float* out, void* stream) {
   return TDG_OK;
 }
 
+__global__ void __launch_bounds__(256) gan_logloss_kernel(const float* __restrict__ dr, const float* __restrict__ df, int n,
+                                                         float* __restrict__ sr, float* __restrict__ sfd, float* __restrict__ sfg,
+                                                         float* __restrict__ scal) {
+  __shared__ float sh[4];
+  float ld = 0.f, lg = 0.f;
+  const float inv = 1.f / (float)n;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float r = dr[i], f = df[i];
+    ld += -logf(r + 1e-8f) - logf(1.f - f + 1e-8f);
+    lg += -logf(f + 1e-8f);
+    sr[i] = -inv / (r + 1e-8f) * r * (1.f - r);
+    sfd[i] = inv / (1.f - f + 1e-8f) * f * (1.f - f);
+    sfg[i] = -inv / (f + 1e-8f) * f * (1.f - f);
+  }
+  ld = block_sum256(ld, sh);
+  lg = block_sum256(lg, sh);
+  if (threadIdx.x == 0) { scal[0] = ld * inv; scal[1] = lg * inv; }
+}
+extern "C" int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, float* seed_real, float* seed_fake_d,
+                               float* seed_fake_g, float* scal, void* stream) {
+  TDG_CHECK_ARG(d_real && d_fake && seed_real && seed_fake_d && seed_fake_g && scal && n > 0, "tdg_gan_logloss: bad argument");
+  hipLaunchKernelGGL(gan_logloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_real, d_fake, n, seed_real, seed_fake_d,
+                     seed_fake_g, scal);
+  TDG_HIP_LAUNCH_CHECK("gan_logloss");
+  return TDG_OK;
+}
+
 __global__ void gp_scalars_kernel(const float* __restrict__ ss, float lambda, float* __restrict__ scal) {
   const float s = sqrtf(ss[0]);
   scal[0] = (s - 1.f) * (s - 1.f);

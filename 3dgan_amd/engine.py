@@ -343,8 +343,14 @@ class SeqNet:
             # dL/d(conv output)
             hw = L.h.h * L.h.w
             if L.spec.use_bn:
+                if want_params:
+                    dbeta = g(L.bn_names[bn_pass])
+                else:                                   # keep the stored beta gradient of an earlier pass intact
+                    if getattr(L, 'dbeta_sink', None) is None:
+                        L.dbeta_sink = torch.zeros(L.spec.out_size, dtype=torch.float32, device=self.device)
+                    dbeta = L.dbeta_sink
                 K.bn_bwd(self.ws, L.gout, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.bn_stats[bn_pass],
-                         L.act.code, L.delta, g(L.bn_names[bn_pass]), rows=rn * hw, leak=L.act.leak, beta_acc=0.0,
+                         L.act.code, L.delta, dbeta, rows=rn * hw, leak=L.act.leak, beta_acc=0.0,
                          dh_ptr=L.gout.ptr(r0), pre_ptr=L.pre.ptr(r0), du_ptr=L.delta.ptr(r0))
             elif L.act.code in (K.ACT_TANH, K.ACT_SIGMOID):
                 _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,

@@ -71,7 +71,7 @@ class GanReplica:
     """The per-GPU replica ("tower") of models/gan.py:55-70 plus its optimizers (:46,79-81)."""
 
     # device scalar slots
-    S_DREAL, S_DFAKE, S_SUMSQ, S_GP, S_GPCOEF, S_GLOSS_AUX = 0, 1, 2, 3, 4, 5
+    S_DREAL, S_DFAKE, S_SUMSQ, S_GP, S_GPCOEF, S_GLOSS_AUX, S_GAN_D, S_GAN_G = 0, 1, 2, 3, 4, 5, 6, 7
 
     def __init__(self, x_source, args, sess):
         self.args, self.sess, self.x_source = args, sess, x_source
@@ -82,8 +82,6 @@ class GanReplica:
         self.B = B
         self.iwgan = self.model == 'iwgan'
         self.display_d_loss = getattr(args, 'display_d_loss', True)
-        if self.model == 'gan':
-            raise NotImplementedError("--model gan (sigmoid log-loss) is not wired to the HIP path yet; use wgan/iwgan")
 
         # ---- build the graph exactly as models/gan.py:55-63 does for one tower
         reset_graph()
@@ -123,6 +121,7 @@ class GanReplica:
         self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
         self._graphs = {}
         self._warm = set()
+        self._seed_g = None
         self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float32, device=dev)
         self.refresh()
@@ -293,9 +292,46 @@ class GanReplica:
             self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
         self.G.backward(0, B, want_params=True)                       # seed = D.dx slot 1 (aliased)
 
+    # -- vanilla GAN: one batch, both updates from the same forward (models/gan.py:110-131) -------------
+    def _gan_grads(self):
+        B, R = self.B, self.B * self.rows_per_image
+        last = self.D.layers[-1]
+        self._rescale_real()
+        self._generate()
+        scores = self._d_forward(0, 2)                               # D(x) with beta set 0, D(g) with beta set 1
+        if self._seed_g is None:
+            self._seed_g = torch.zeros(R, dtype=torch.float32, device=self.sess.device)
+        _lib.call('tdg_gan_logloss', K.ptr(scores, 0), K.ptr(scores, 4 * R), R, K.ptr(last.seed, 0), K.ptr(last.seed, 4 * R),
+                  K.ptr(self._seed_g), K.ptr(self.scal, 4 * self.S_GAN_D), K.stream())
+        self.D.backward(0, B, bn_pass=0, want_params=True, acc=False)
+        self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
+        # generator: same forward, g_loss seed on the fake scores, gradient w.r.t. g only
+        last.seed[R:2 * R].copy_(self._seed_g)
+        self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
+        self.G.backward(0, B, want_params=True)
+
+    def _gan_apply(self):
+        self.d_opt.step(self._scale)
+        self.g_opt.step(self._scale)
+        self.D.repack()
+        self.G.repack()
+
+    def gan_step(self, x01):
+        self._load_real(x01)
+        self._run('gan_grads', self._gan_grads)
+        self.sess.assert_finite(self.d_store, 'gan_step')
+        self.sess.assert_finite(self.g_store, 'gan_step')
+        self._scale = average_gradients(self.sess, self.d_store)
+        average_gradients(self.sess, self.g_store)
+        self._run('gan_apply', self._gan_apply)
+        self.sess.global_step += 2                                    # both apply ops bump it (models/gan.py:80-81)
+
     def losses(self):
-        """Host read-back of the device scalars (one sync): models/gan.py:196-205."""
+        """Host read-back of the device scalars (one sync): models/gan.py:193-205."""
         s = self.scal.cpu().tolist()
+        if self.model == 'gan':
+            return collection_to_dict([('tower_%d/g_loss:0' % self.sess.rank, s[self.S_GAN_G]),
+                                       ('tower_%d/d_loss:0' % self.sess.rank, s[self.S_GAN_D])])
         g_loss = -s[self.S_DFAKE]
         d_loss = s[self.S_DFAKE] - s[self.S_DREAL]
         if self.iwgan:
@@ -307,6 +343,9 @@ class GanReplica:
         """_train_wgan / _train_iwgan helper (models/gan.py:150-155,169-173): n_disc_train D steps,
         then one G step, each on a fresh batch; returns the loss dict of the G step's batch."""
         args = args or self.args
+        if self.model == 'gan':                                       # _train_gan: one run of both train ops
+            self.gan_step(self.x_source.next_batch())
+            return self.losses()
         for _ in range(args.n_disc_train):
             self.d_step(self.x_source.next_batch())
         self.g_step(self.x_source.next_batch())

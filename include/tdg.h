@@ -155,6 +155,11 @@ int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* 
 size_t tdg_reduce_workspace_bytes(size_t n);
 /* out[0] = mean(x[0:n]) f32 input (tf.reduce_mean of D outputs, models/gan.py:196-204) */
 int tdg_mean_f32(const float* x, int n, float* out, void* stream);
+/* Vanilla-GAN losses on post-sigmoid scores (models/gan.py:193-194) and their gradients w.r.t. the LOGITS:
+ *   scal[0] = d_loss = mean(-log(dr+1e-8) - log(1-df+1e-8)),  scal[1] = g_loss = mean(-log(df+1e-8))
+ *   seed_real = d d_loss/d logit_real, seed_fake_d = d d_loss/d logit_fake, seed_fake_g = d g_loss/d logit_fake */
+int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, float* seed_real, float* seed_fake_d,
+                    float* seed_fake_g, float* scal, void* stream);
 /* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
  * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);

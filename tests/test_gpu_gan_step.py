@@ -168,3 +168,32 @@ def test_graph_replay_matches_eager():
     assert oa == ob
     for k in va:
         assert np.array_equal(va[k], vb[k]), k
+
+
+BN_FED_BIASES = {'generator/vars/%s/bias' % n for n in ('fc1', 'dc1', 'dc2', 'dc3')} | \
+    {'discriminator/vars/%s/bias' % n for n in ('c2', 'c3')}
+
+
+def test_vanilla_gan_step_f32():
+    """--model gan: one batch, D and G gradients from the same forward (models/gan.py:110-131,193-194)."""
+    args, cfg, P, batches, zs, alphas, sess, rep = build('gan', 0, optimizer='rmsprop')
+    tr = G.GanTrainer({k: v.copy() for k, v in P.items()}, cfg, args)
+    sess.inject = {'z': [zs[0]]}
+    out = rep.train_func()
+    x = tr.rescale(batches[0].astype(np.float64))
+    dl, dg, _ = G.d_loss_and_grads(P, x, zs[0].astype(np.float64), None, cfg)
+    gl, gg, _ = G.g_loss_and_grads(P, zs[0].astype(np.float64), cfg)
+    got = rep.gradients()
+    for grads in (dg, gg):
+        for k, g in grads.items():
+            if k in BN_FED_BIASES:
+                continue                   # biases under batch norm: zero gradient up to rounding
+            assert relerr(got[k], g) < 1e-3, k
+    assert abs(out['d_loss'] - dl) < 1e-3 * max(1, abs(dl)) and abs(out['g_loss'] - gl) < 1e-3 * max(1, abs(gl))
+    ref = tr.train_func([batches[0].astype(np.float64)], [zs[0].astype(np.float64)])
+    new = rep.variables()
+    for k in list(dg) + list(gg):
+        if k in BN_FED_BIASES:
+            continue
+        assert relerr(new[k], tr.P[k]) < 1e-3, k
+    assert sess.global_step == 2
