@@ -635,6 +635,102 @@ extern "C" int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, 
   return TDG_OK;
 }
 
+// ---- VAE ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) vae_reparam_kernel(const T* __restrict__ heads, int hs, const T* __restrict__ eps, int es,
+                                                         int rows, int L, T* __restrict__ z, int zs) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * L; i += gridDim.x * 256) {
+    const int r = i / L, c = i - r * L;
+    z[(size_t)r * zs + c] = from_f32<T>(to_f32<T>(heads[(size_t)r * hs + c]) +
+                                       to_f32<T>(heads[(size_t)r * hs + L + c]) * to_f32<T>(eps[(size_t)r * es + c]));
+  }
+}
+extern "C" int tdg_vae_reparam(int dtype, const void* heads, int hs, const void* eps, int es, int rows, int L, void* z, int zs,
+                               void* stream) {
+  TDG_CHECK_ARG(heads && eps && z && rows > 0 && L > 0 && hs >= 2 * L && es >= L && zs >= L, "tdg_vae_reparam: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(vae_reparam_kernel<T>, dim3(ew_blocks((size_t)rows * L, 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(heads), hs, static_cast<const T*>(eps), es, rows, L, static_cast<T*>(z), zs);
+  })
+  TDG_HIP_LAUNCH_CHECK("vae_reparam");
+  return TDG_OK;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) vae_reparam_bwd_kernel(const T* __restrict__ dz, int zs, const T* __restrict__ eps, int es,
+                                                             int rows, int L, T* __restrict__ dh, int hs) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * L; i += gridDim.x * 256) {
+    const int r = i / L, c = i - r * L;
+    const float g = to_f32<T>(dz[(size_t)r * zs + c]);
+    dh[(size_t)r * hs + c] = from_f32<T>(g);
+    dh[(size_t)r * hs + L + c] = from_f32<T>(g * to_f32<T>(eps[(size_t)r * es + c]));
+  }
+}
+extern "C" int tdg_vae_reparam_bwd(int dtype, const void* dz, int zs, const void* eps, int es, int rows, int L, void* dheads,
+                                   int hs, void* stream) {
+  TDG_CHECK_ARG(dz && eps && dheads && rows > 0 && L > 0 && hs >= 2 * L && es >= L && zs >= L, "tdg_vae_reparam_bwd: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(vae_reparam_bwd_kernel<T>, dim3(ew_blocks((size_t)rows * L, 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(dz), zs, static_cast<const T*>(eps), es, rows, L, static_cast<T*>(dheads), hs);
+  })
+  TDG_HIP_LAUNCH_CHECK("vae_reparam_bwd");
+  return TDG_OK;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) vae_kl_partial_kernel(const T* __restrict__ heads, int hs, int rows, int L,
+                                                            float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * L; i += gridDim.x * 256) {
+    const int r = i / L, c = i - r * L;
+    const float m = to_f32<T>(heads[(size_t)r * hs + c]), sd = to_f32<T>(heads[(size_t)r * hs + L + c]);
+    s += m * m + sd * sd - logf(1e-8f + sd * sd) - 1.f;
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" int tdg_vae_kl(int dtype, const void* heads, int hs, int rows, int L, float* scal, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(heads && scal && workspace && rows > 0 && L > 0 && hs >= 2 * L, "tdg_vae_kl: bad argument");
+  if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_vae_kl: workspace too small"); return TDG_EWORKSPACE; }
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(vae_kl_partial_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(heads),
+                       hs, rows, L, static_cast<float*>(workspace));
+  })
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
+                     RED_BLOCKS, scal, 0.f, 0.5f);
+  TDG_HIP_LAUNCH_CHECK("vae_kl");
+  return TDG_OK;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) vae_bce_kernel(const float* __restrict__ x, const T* __restrict__ d, size_t n, int c, int cs,
+                                                     T* __restrict__ seed, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c;
+    const int ch = (int)(i - r * c);
+    const size_t j = r * cs + ch;
+    const float xv = x[i], dv = to_f32<T>(d[j]);
+    s -= xv * logf(1e-8f + dv) + (1.f - xv) * logf(1e-8f + (1.f - dv));
+    seed[j] = from_f32<T>(-(xv / (1e-8f + dv) - (1.f - xv) / (1e-8f + (1.f - dv))));
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" int tdg_vae_bce(int dtype, const float* x, const void* d, int rows, int c, int cs, void* seed, float* scal,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(x && d && seed && scal && workspace && rows > 0 && c > 0 && cs >= c, "tdg_vae_bce: bad argument");
+  if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_vae_bce: workspace too small"); return TDG_EWORKSPACE; }
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(vae_bce_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, static_cast<const T*>(d),
+                       (size_t)rows * c, c, cs, static_cast<T*>(seed), static_cast<float*>(workspace));
+  })
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
+                     RED_BLOCKS, scal, 0.f, 1.f);
+  TDG_HIP_LAUNCH_CHECK("vae_bce");
+  return TDG_OK;
+}
+
 __global__ void gp_scalars_kernel(const float* __restrict__ ss, float lambda, float* __restrict__ scal) {
   const float s = sqrtf(ss[0]);
   scal[0] = (s - 1.f) * (s - 1.f);

@@ -4,4 +4,5 @@
 def model_funcs():
     """The dispatch table of train.py:240-244."""
     from .gan import gan
-    return {'gan': gan, 'wgan': gan, 'iwgan': gan}
+    from .vae import vae
+    return {'gan': gan, 'wgan': gan, 'iwgan': gan, 'vae': vae}

@@ -1,0 +1,209 @@
+"""Convolutional VAE on MI355X -- the builder surface of the reference's `models/vae.py`
+(vae :25-51, losses :66-90, encoder :93-110, latent :113-129, decoder :132-151) on the HIP kernels.
+
+Kept: `vae(x, args)` returns `train_func(sess, args) -> {'decoder_loss', 'latent_loss', 'total_loss'}`
+(util.py:22-28 default_training: one batch per call); encoder/latent/decoder are written against
+dense/conv2d/deconv2d + arg_scope as in the reference; variable names
+(`encoder/vars/c1/weights`, `latent/vars/d1/weights`, `decoder/vars/dc4/bias`, ...).
+
+Effective semantics reproduced: only `decoder_loss` is differentiated
+(models/vae.py:41); the KL term is reported, not optimised; z_stddev is an unconstrained linear head;
+the second decoder pass on `samples` (:37) exists only for image summaries and is not executed.
+
+MI355X-native: the two latent heads (d1, d2 read the same 512-vector) run as ONE GEMM with 2L output
+columns; z = mean + std * eps and its backward are tiny fused kernels; the BCE sum and its seed are
+one pass; everything else is the shared implicit-GEMM / batch-norm kernel set.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from .. import kernels as K
+from .. import engine
+from ..ops.layers import dense, conv2d, deconv2d, flatten, reshape, random_normal, arg_scope, variable_scope, placeholder, reset_graph
+from ..ops.activations import lrelu, relu, sigmoid
+from ..util import tower_scope_range, average_gradients, init_optimizer, collection_to_dict
+
+
+def encoder(x, reuse=False):
+    """models/vae.py:93-110."""
+    with arg_scope([conv2d], reuse=reuse, activation=lrelu, use_batch_norm=True):
+        x = conv2d(x, x.shape[-1], 64, 5, 2, name='c1')
+        x = conv2d(x, 64, 128, 5, 2, name='c2')
+        x = conv2d(x, 128, 256, 5, 2, name='c3')
+        x = conv2d(x, 256, 256, 5, 2, name='c4')
+        x = conv2d(x, 256, 96, 1, name='c5')
+        x = conv2d(x, 96, 32, 1, name='c6')
+    return x
+
+
+def latent(x, batch_size, latent_size, reuse=False):
+    """models/vae.py:113-129."""
+    with arg_scope([dense], reuse=reuse):
+        flat = flatten(x)
+        z_mean = dense(flat, 32 * 4 * 4, latent_size, name='d1')
+        z_stddev = dense(flat, 32 * 4 * 4, latent_size, name='d2')
+        samples = random_normal([batch_size, latent_size])
+        z = (z_mean, z_stddev, samples)                 # z_mean + z_stddev * samples, fused at run time
+    return (samples, z, z_mean, z_stddev)
+
+
+def decoder(x, latent_size, out_channels=3, reuse=False):
+    """models/vae.py:132-151."""
+    with arg_scope([dense, conv2d, deconv2d], activation=relu, reuse=reuse):
+        x = dense(x, latent_size, 32 * 4 * 4, name='d1')
+        x = reshape(x, [-1, 4, 4, 32])
+        x = conv2d(x, 32, 96, 1, name='c1')
+        x = conv2d(x, 96, 256, 1, name='c2')
+        x = deconv2d(x, 256, 256, 5, 2, name='dc1')
+        x = deconv2d(x, 256, 128, 5, 2, name='dc2')
+        x = deconv2d(x, 128, 64, 5, 2, name='dc3')
+        x = deconv2d(x, 64, out_channels, 5, 2, name='dc4', activation=sigmoid)
+    return x
+
+
+class VaeReplica:
+    S_DLOSS, S_LLOSS = 0, 1
+
+    def __init__(self, x_source, args, sess):
+        self.args, self.sess, self.x_source = args, sess, x_source
+        B, L = args.batch_size, args.latent_size
+        h, w, c = args.image_shape
+        if (h, w) != (64, 64):
+            raise ValueError('models/vae.py is hard-wired to 64x64 inputs (32*4*4 features, :125); use --resize 64 64')
+        dev, dt = sess.device, sess.dtype
+        self.B, self.L = B, L
+
+        reset_graph()
+        x_sym = placeholder((None, h, w, c))
+        for _x, scope, gpu_id in tower_scope_range(x_sym, args.n_gpus, B, sess):
+            with variable_scope('encoder') as enet:
+                e = encoder(_x, reuse=False)
+            with variable_scope('latent') as lnet:
+                samples, z, z_mean, z_stddev = latent(e, B, L, reuse=False)
+            with variable_scope('decoder') as dnet:
+                d_real = decoder(placeholder((None, L)), L, c, reuse=False)
+        self.enet, self.lnet, self.dnet = enet, lnet, dnet
+
+        self.ws = K.Workspace(dev)
+        self.store = engine.ParamStore(dev)                       # ONE optimizer over every variable (models/vae.py:26,41)
+        self.E = engine.SeqNet(enet, B, (h, w, c), dt, dev, self.store, ws=self.ws)
+        self.Dn = engine.SeqNet(dnet, B, (1, 1, L), dt, dev, self.store, need_input_grad=True, ws=self.ws)
+        self.E.declare_variables()
+        for l in lnet.layers:                                       # latent/vars/d1, d2 under their own names
+            self.store.declare(lnet.var_name(l, 'weights'), l.filter_shape)
+            self.store.declare(lnet.var_name(l, 'bias'), (l.out_size,))
+        self.Dn.declare_variables()
+        self.store.allocate()
+        gen = torch.Generator().manual_seed(sess.seed)
+        self.E.init_variables(gen)
+        for l in lnet.layers:
+            for which, shape in (('weights', l.filter_shape), ('bias', (l.out_size,))):
+                cpu = torch.empty(shape)
+                engine.xavier_uniform_(cpu, shape, gen)
+                self.store[lnet.var_name(l, which)].copy_(cpu)
+        self.Dn.init_variables(gen)
+        self.opt = init_optimizer(args, self.store)
+
+        # fused latent heads: flat [B,512] -> [B, 2L] = [mean | std]
+        e_last = self.E.layers[-1]
+        self.flat = K.Act(B, 1, 1, 512, dt, dev, 512, e_last.h.buf)
+        self.dflat = K.Act(B, 1, 1, 512, dt, dev, 512, e_last.gout.buf)
+        self.heads = K.Act(B, 1, 1, 2 * L, dt, dev)
+        self.dheads = self.heads.like()
+        self.head_conv = K.Conv(self.flat, self.heads, 1, 1, 1, 0, 0)
+        self.w_heads = torch.zeros(512, 2 * L, dtype=torch.float32, device=dev)
+        self.b_heads = torch.zeros(2 * L, dtype=torch.float32, device=dev)
+        self.dw_heads = torch.zeros_like(self.w_heads)
+        self.db_heads = torch.zeros_like(self.b_heads)
+        self.eps = K.Act(B, 1, 1, L, dt, dev)
+        self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.refresh()
+
+    # ---- variables -----------------------------------------------------------------------------------
+    def stores(self):
+        return [self.store]
+
+    def optimizers(self):
+        return {'optimizers/vae': self.opt}
+
+    def refresh(self):
+        L = self.L
+        self.E.repack()
+        self.Dn.repack()
+        self.w_heads[:, :L].copy_(self.store['latent/vars/d1/weights'])
+        self.w_heads[:, L:].copy_(self.store['latent/vars/d2/weights'])
+        self.b_heads[:L].copy_(self.store['latent/vars/d1/bias'])
+        self.b_heads[L:].copy_(self.store['latent/vars/d2/bias'])
+        self.head_conv.pack(self.w_heads, fwd=True, bwd=True)
+
+    def load_variables(self, arrays):
+        self.store.load(arrays)
+        self.refresh()
+
+    def variables(self):
+        return self.store.state_dict()
+
+    def gradients(self):
+        return self.store.grads_dict()
+
+    # ---- one training step (util.py:22-28 default_training) -------------------------------------------------
+    def step(self, x01):
+        B, L, dt = self.B, self.L, self.sess.dtype
+        h, w, c = self.args.image_shape
+        self.x_stage.copy_(x01.reshape(self.x_stage.shape))
+        _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), B * h * w, c, self.E.x.cs, 1.0, 0.0, self.E.x.ptr(0), K.stream())
+        self.E.forward(0, B)
+        self.head_conv.fwd(self.flat.ptr(), self.heads.ptr(), B, K.epilogue(bias=self.b_heads))
+        self.sess.random_normal(self.eps, B, 'eps')                                              # models/vae.py:127
+        _lib.call('tdg_vae_reparam', dt, self.heads.ptr(), self.heads.cs, self.eps.ptr(), self.eps.cs, B, L,
+                  self.Dn.x.ptr(), self.Dn.x.cs, K.stream())                                     # :128
+        d = self.Dn.forward(0, B)
+        last = self.Dn.layers[-1]
+        wsb = self.ws.ensure(4096)
+        _lib.call('tdg_vae_bce', dt, K.ptr(self.x_stage), d.ptr(), B * h * w, c, d.cs, last.gout.ptr(),
+                  K.ptr(self.scal, 4 * self.S_DLOSS), K.ptr(wsb), wsb.numel(), K.stream())       # :76-77
+        _lib.call('tdg_vae_kl', dt, self.heads.ptr(), self.heads.cs, B, L, K.ptr(self.scal, 4 * self.S_LLOSS), K.ptr(wsb),
+                  wsb.numel(), K.stream())                                                       # :80-81 (reported only)
+        # backward of decoder_loss only (:41)
+        self.Dn.backward(0, B, want_params=True, want_dx=True)
+        _lib.call('tdg_vae_reparam_bwd', dt, self.Dn.dx.ptr(), self.Dn.dx.cs, self.eps.ptr(), self.eps.cs, B, L,
+                  self.dheads.ptr(), self.dheads.cs, K.stream())
+        K.bias_grad(self.ws, self.dheads, 2 * L, self.db_heads, rows=B)
+        self.head_conv.bwd_filter(self.flat.ptr(), self.dheads.ptr(), self.dw_heads, B, 0.0)
+        self.head_conv.bwd_data(self.dheads.ptr(), self.dflat.ptr(), B)
+        g = self.store.grad
+        g('latent/vars/d1/weights').copy_(self.dw_heads[:, :L])
+        g('latent/vars/d2/weights').copy_(self.dw_heads[:, L:])
+        g('latent/vars/d1/bias').copy_(self.db_heads[:L])
+        g('latent/vars/d2/bias').copy_(self.db_heads[L:])
+        self.E.backward(0, B, want_params=True)
+        self.sess.assert_finite(self.store, 'vae_step')
+        scale = average_gradients(self.sess, self.store)
+        self.opt.step(scale)
+        self.sess.global_step += 1
+        self.refresh()
+
+    def losses(self):
+        s = self.scal.cpu().tolist()
+        r = self.sess.rank
+        return collection_to_dict([('tower_%d/decoder_loss:0' % r, s[self.S_DLOSS]), ('tower_%d/latent_loss:0' % r, s[self.S_LLOSS]),
+                                   ('tower_%d/total_loss:0' % r, s[self.S_DLOSS] + s[self.S_LLOSS])])
+
+    def train_func(self, sess=None, args=None):
+        self.step(self.x_source.next_batch())
+        return self.losses()
+
+
+def vae(x, args, sess=None):
+    """models/vae.py:25-51."""
+    from ..runtime import Session
+    sess = sess or Session(dtype=getattr(args, 'dtype_code', K.BF16), seed=getattr(args, 'seed', 0) or 0)
+    replica = VaeReplica(x, args, sess)
+
+    def train_func(sess_=None, args_=None):
+        return replica.train_func(sess_, args_)
+    train_func.replica = replica
+    return train_func

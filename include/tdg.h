@@ -160,6 +160,20 @@ int tdg_mean_f32(const float* x, int n, float* out, void* stream);
  *   seed_real = d d_loss/d logit_real, seed_fake_d = d d_loss/d logit_fake, seed_fake_g = d g_loss/d logit_fake */
 int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, float* seed_real, float* seed_fake_d,
                     float* seed_fake_g, float* scal, void* stream);
+/* ---- VAE pieces (models/vae.py:66-90,113-129) -------------------------------------------------------
+ * heads = [z_mean | z_stddev] rows of 2L (channel stride hs); z = mean + stddev * eps (models/vae.py:128) */
+int tdg_vae_reparam(int dtype, const void* heads, int hs, const void* eps, int es, int rows, int L, void* z, int zs,
+                    void* stream);
+/* dheads = [dz | dz * eps] */
+int tdg_vae_reparam_bwd(int dtype, const void* dz, int zs, const void* eps, int es, int rows, int L, void* dheads, int hs,
+                        void* stream);
+/* scal[0] = latent_loss = 0.5 * sum(mean^2 + std^2 - log(1e-8 + std^2) - 1)  (models/vae.py:80-81) */
+int tdg_vae_kl(int dtype, const void* heads, int hs, int rows, int L, float* scal, void* workspace, size_t workspace_bytes,
+               void* stream);
+/* scal[0] = decoder_loss = -sum(x log(1e-8+d) + (1-x) log(1e-8+1-d)) (models/vae.py:76-77);
+ * seed = d decoder_loss / d d.  x: compact f32 [rows, c] in [0,1]; d, seed: [rows, cs] in dtype. */
+int tdg_vae_bce(int dtype, const float* x, const void* d, int rows, int c, int cs, void* seed, float* scal, void* workspace,
+                size_t workspace_bytes, void* stream);
 /* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
  * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);

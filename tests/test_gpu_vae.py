@@ -1,0 +1,64 @@
+"""GPU parity of the VAE step (models/vae.py semantics) against the NumPy oracle on injected inputs."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import vae_ref as V
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def test_vae_step_f32():
+    vae, rt, data, K = pkg('models.vae'), pkg('runtime'), pkg('data'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    B, L = 3, 8
+    args = SimpleNamespace(model='vae', batch_size=B, latent_size=L, image_shape=(64, 64, 3), n_gpus=1, optimizer='rmsprop',
+                           lr=1e-3, decay=0.9, momentum=0.01, centered=False, beta1=0.9, beta2=0.999)
+    P = V.init_params(L, 0, np.float64)
+    rng = np.random.default_rng(2)
+    xs = [rng.uniform(0, 1, (B, 64, 64, 3)).astype(np.float32) for _ in range(2)]
+    eps = [rng.standard_normal((B, L)).astype(np.float32) for _ in range(2)]
+    sess = rt.Session(device=dev, dtype=K.F32, seed=0, rank=0, world_size=1)
+    rep = vae.VaeReplica(data.ArraySource(np.concatenate(xs), B, dev), args, sess)
+    assert set(rep.store.index) == set(V.param_shapes(L))
+    rep.load_variables({k: v.astype(np.float32) for k, v in P.items()})
+    tr = V.VaeTrainer({k: v.copy() for k, v in P.items()}, args)
+    for it in range(2):
+        sess.inject = {'eps': [eps[it]]}
+        losses, c = V.forward(tr.P, xs[it].astype(np.float64), eps[it].astype(np.float64))
+        grads = V.backward(tr.P, c)
+        out = rep.train_func()
+        got = rep.gradients()
+        for k, g in grads.items():
+            if k.startswith('encoder/vars/') and k.endswith('/bias'):
+                continue                     # biases feeding batch norm: zero gradient up to rounding
+            assert relerr(got[k], g) < 1e-3, (it, k)
+        for k in ('decoder_loss', 'latent_loss', 'total_loss'):
+            assert abs(out[k] - losses[k]) < 1e-3 * max(1.0, abs(losses[k])), (it, k, out[k], losses[k])
+        tr.train_func(xs[it].astype(np.float64), eps[it].astype(np.float64))
+        new = rep.variables()
+        for k in grads:
+            if k.startswith('encoder/vars/') and k.endswith('/bias'):
+                continue
+            assert relerr(new[k], tr.P[k]) < 1e-3, (it, k)
+    assert set(out) == {'decoder_loss', 'latent_loss', 'total_loss'}
+
+
+def test_vae_bf16_runs_and_loss_decreases():
+    vae, rt, data, K = pkg('models.vae'), pkg('runtime'), pkg('data'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    args = SimpleNamespace(model='vae', batch_size=16, latent_size=32, image_shape=(64, 64, 3), n_gpus=1, optimizer='adam',
+                           lr=1e-3, decay=0.9, momentum=0.01, centered=False, beta1=0.9, beta2=0.999)
+    sess = rt.Session(device=dev, dtype=K.BF16, seed=1, rank=0, world_size=1)
+    rep = vae.VaeReplica(data.SyntheticSource(16, (64, 64, 3), 16, dev, seed=3), args, sess)
+    first = rep.train_func()['decoder_loss']
+    for _ in range(30):
+        last = rep.train_func()['decoder_loss']
+    assert np.isfinite(last) and last < first
