@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
 class Epilogue(C.Structure):
     """TdgEpilogue (include/tdg.h)."""
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('leak', C.c_float),
-                ('mask_mode', C.c_int32), ('mask_src', C.c_void_p)]
+                ('mask_mode', C.c_int32), ('mask_src', C.c_void_p), ('accumulate', C.c_int32)]
 
 
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -49,8 +49,8 @@ SIGNATURES = {
     'tdg_colsum_weighted': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_colsum_workspace_bytes': (_sz, [_i, _i]),
     'tdg_bn_workspace_bytes': (_sz, [_i, _i]),
-    'tdg_bn_fwd': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'tdg_bn_bwd': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _sz, _vp]),
+    'tdg_bn_fwd': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    'tdg_bn_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_bias_act': (_i, [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp]),
     'tdg_act_bwd': (_i, [_i, _vp, _vp, _sz, _i, _f, _vp, _vp]),
     'tdg_affine_cast': (_i, [_i, _vp, _sz, _f, _f, _vp, _vp]),

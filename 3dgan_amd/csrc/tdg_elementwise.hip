@@ -60,12 +60,14 @@ __device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
 // channels (one 8/16-byte load per row when VW = 4).
 struct ColGeom {
   int rows, C, cs, nblk, rows_per_blk, CL, ncol, vw;  // CL = channel lanes (power of two <= 64)
+  int xcs;                                              // row stride of the primary tensor (defaults to cs)
 };
-static inline ColGeom col_geom(int rows, int C, int cs, const void* p0 = nullptr, const void* p1 = nullptr, int es = 4) {
+static inline ColGeom col_geom(int rows, int C, int cs, const void* p0 = nullptr, const void* p1 = nullptr, int es = 4,
+                               bool allow_vec = true) {
   ColGeom g;
-  g.rows = rows; g.C = C; g.cs = cs;
+  g.rows = rows; g.C = C; g.cs = cs; g.xcs = cs;
   const bool al = (((uintptr_t)p0 | (uintptr_t)p1) % (4 * es)) == 0;
-  g.vw = (C % 4 == 0 && cs % 4 == 0 && al) ? 4 : 1;
+  g.vw = (allow_vec && C % 4 == 0 && cs % 4 == 0 && al) ? 4 : 1;
   const int cv = (C + g.vw - 1) / g.vw;
   int cl = 1;
   while (cl < cv && cl < 64) cl <<= 1;
@@ -131,7 +133,7 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
     for (int r = r0 + ty; r < r1; r += RL) {
       const size_t i = (size_t)r * g.cs + c;
       float v[VW];
-      load_vw<T, VW>(x + i, v);
+      load_vw<T, VW>(x + (size_t)r * g.xcs + c, v);
       if (MODE == COL_BN_STATS) {
 #pragma unroll
         for (int e = 0; e < VW; ++e) { const float d = v[e] - pivot[e]; s0[e] += d; s1[e] += d * d; }
@@ -228,7 +230,7 @@ __device__ __forceinline__ void store_vw(T* p, const float (&v)[VW]) {
 template <typename T, int VW>
 __global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, const T* __restrict__ u,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
-                                                          int act, float leak, T* __restrict__ pre, T* __restrict__ h) {
+                                                          int act, float leak, T* __restrict__ pre, T* __restrict__ h, int hcs) {
   const int CL = g.CL, RL = 256 / CL, C = g.C;
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int c = (blockIdx.y * CL + tx) * VW;
@@ -243,12 +245,12 @@ __global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, cons
 #pragma unroll
     for (int e = 0; e < VW; ++e) { p[e] = (v[e] - mean[e]) * rstd[e] + b[e]; a[e] = apply_act(p[e], act, leak); }
     store_vw<T, VW>(pre + i, p);
-    store_vw<T, VW>(h + i, a);
+    store_vw<T, VW>(h + (size_t)r * hcs + c, a);
   }
 }
 
 template <typename T, int VW>
-__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, const T* __restrict__ dh, const T* __restrict__ pre,
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, const T* __restrict__ dh, int dhcs, const T* __restrict__ pre,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
                                                           const float* __restrict__ sums, int act, float leak, T* __restrict__ du) {
   const int CL = g.CL, RL = 256 / CL, C = g.C;
@@ -261,7 +263,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, cons
   for (int r = blockIdx.x * RL + ty; r < g.rows; r += gridDim.x * RL) {
     const size_t i = (size_t)r * g.cs + c;
     float d[VW], p[VW], o[VW];
-    load_vw<T, VW>(dh + i, d);
+    load_vw<T, VW>(dh + (size_t)r * dhcs + c, d);
     load_vw<T, VW>(pre + i, p);
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
@@ -296,10 +298,10 @@ static int run_col_partial(const ColGeom& g, const ColArgs& a, hipStream_t s) {
 }
 
 extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
-                          float leak, void* pre, void* h, float* stats, void* workspace, size_t workspace_bytes,
+                          float leak, void* pre, void* h, int h_cs, float* stats, void* workspace, size_t workspace_bytes,
                           void* stream) {
   TDG_CHECK_ARG(u && beta && pre && h && stats && workspace, "tdg_bn_fwd: null pointer");
-  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_fwd: bad shape rows=%d c=%d cs=%d", rows, c, cs);
+  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c && h_cs >= c, "tdg_bn_fwd: bad shape rows=%d c=%d cs=%d h_cs=%d", rows, c, cs, h_cs);
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_fwd: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
   const ColGeom g = col_geom(rows, c, cs, u, nullptr, tdg_dtype_size(dtype));
@@ -307,7 +309,7 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
   a.x = u; a.partial = static_cast<float*>(workspace);
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.x0 = u; f.eps = eps; f.out0 = stats;
-  ColGeom ga = col_geom(rows, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), tdg_dtype_size(dtype));
+  const ColGeom ga = col_geom(rows, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), tdg_dtype_size(dtype), h_cs % 4 == 0);
   const dim3 agrid(apply_row_blocks(ga), ga.ncol);
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_STATS>(g, a, s);
@@ -315,39 +317,41 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
     hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + 31) / 32), dim3(256), 0, s, f);
     if (ga.vw == 4)
       hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
-                         leak, static_cast<T*>(pre), static_cast<T*>(h));
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
     else
       hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
-                         leak, static_cast<T*>(pre), static_cast<T*>(h));
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
   })
   TDG_HIP_LAUNCH_CHECK("bn_fwd");
   return TDG_OK;
 }
 
-extern "C" int tdg_bn_bwd(int dtype, const void* dh, const void* pre, int rows, int c, int cs, const float* beta,
+extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre, int rows, int c, int cs, const float* beta,
                           const float* stats, int act, float leak, void* du, float* dbeta, float beta_acc,
                           void* workspace, size_t workspace_bytes, void* stream) {
   TDG_CHECK_ARG(dh && pre && beta && stats && du && dbeta && workspace, "tdg_bn_bwd: null pointer");
-  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c, "tdg_bn_bwd: bad shape");
+  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c && dh_cs >= c, "tdg_bn_bwd: bad shape");
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_bwd: workspace too small"); return TDG_EWORKSPACE; }
   hipStream_t s = (hipStream_t)stream;
-  const ColGeom g = col_geom(rows, c, cs, dh, pre, tdg_dtype_size(dtype));
+  ColGeom g = col_geom(rows, c, cs, dh, pre, tdg_dtype_size(dtype), dh_cs % 4 == 0);
+  g.xcs = dh_cs;
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = dh; a.y = pre; a.beta = beta; a.act = act; a.leak = leak; a.partial = static_cast<float*>(workspace);
   float* sums = a.partial + (size_t)g.nblk * 2 * c;
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.out0 = dbeta; f.out1 = sums; f.beta_acc = beta_acc;
-  ColGeom ga = col_geom(rows, c, cs, dh, (const void*)((uintptr_t)pre | (uintptr_t)du), tdg_dtype_size(dtype));
+  ColGeom ga = col_geom(rows, c, cs, dh, (const void*)((uintptr_t)pre | (uintptr_t)du), tdg_dtype_size(dtype), dh_cs % 4 == 0);
+  ga.xcs = dh_cs;
   const dim3 agrid(apply_row_blocks(ga), ga.ncol);
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
     if (rc) return rc;
     hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + 31) / 32), dim3(256), 0, s, f);
     if (ga.vw == 4)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh),
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
                          static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
     else
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh),
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
                          static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
   })
   TDG_HIP_LAUNCH_CHECK("bn_bwd");

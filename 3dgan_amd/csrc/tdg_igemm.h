@@ -35,7 +35,7 @@ struct IgArgs {
   int C, Cs;             // channels per tap in K (effective, multiple of VEC on the vector path), channel stride
   FastDiv fd_c;          // divide by C (scalar path) or by C/VEC (vector path)
   int N, OH, OW, os, Cso;
-  int act, mask_mode;
+  int act, mask_mode, accumulate;
   float leak;
   int ntiles_n, ntiles_m_max, nclasses;
   int debug;             // TDG_DEBUG_ABLATE (diagnostics only): 1 no global loads in loop, 2 + no LDS stores, 3 no MFMA

@@ -273,6 +273,17 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], args.act, args.leak);
+        if (args.accumulate) {
+          if constexpr (sizeof(T) == 4) {
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(out + pix + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += ov[e];
+          } else {
+            const bf16x4 ov = *reinterpret_cast<const bf16x4*>(out + pix + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)ov[e];
+          }
+        }
         if (args.mask_mode != TDG_MASK_NONE) {
           if constexpr (sizeof(T) == 4) {
             const f32x4 mv = *reinterpret_cast<const f32x4*>(msk + pix + n);
@@ -295,6 +306,7 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
           if (n + e < N) {
             float x = v[e] + (args.bias ? args.bias[n + e] : 0.f);
             x = apply_act(x, args.act, args.leak);
+            if (args.accumulate) x += to_f32<T>(out[pix + n + e]);
             if (args.mask_mode != TDG_MASK_NONE) x *= mask_factor(to_f32<T>(msk[pix + n + e]), args.mask_mode, args.leak);
             out[pix + n + e] = from_f32<T>(x);
           }
@@ -502,7 +514,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   T* out = static_cast<T*>(args.out);
   const T* msk = static_cast<const T*>(args.mask_src);
   const float* bias = args.bias;
-  const int act = args.act, mmode = args.mask_mode;
+  const int act = args.act, mmode = args.mask_mode, accum = args.accumulate;
   const float leak = args.leak;
   size_t pix[TM];
   bool okm[TM];
@@ -530,6 +542,15 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
         f32x4 v = acc[i][j] + bv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, leak);
+        if (accum) {
+          if constexpr (sizeof(T) == 4) {
+            v += *reinterpret_cast<const f32x4*>(out + pix[i] + n);
+          } else {
+            const bf16x4 ov = *reinterpret_cast<const bf16x4*>(out + pix[i] + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)ov[e];
+          }
+        }
         if (mmode != TDG_MASK_NONE) {
           if constexpr (sizeof(T) == 4) {
             const f32x4 mv = *reinterpret_cast<const f32x4*>(msk + pix[i] + n);
@@ -998,7 +1019,13 @@ int validate_desc(const TdgConvDesc* d, const char* who) {
 }
 
 // effective channel count of a tensor side for the vector gather (0 -> scalar path)
-inline int eff_channels(int c, int cs, int vec) { (void)c; return cs % vec == 0 ? cs : 0; }
+// channels per tap seen by the 16-byte gather: c rounded up to a whole vector, provided the row stride
+// keeps vectors aligned and has room for the round-up (the extra channels are zeros or a neighbouring
+// channel window, and meet zero filter entries either way); 0 -> element-wise gather
+inline int eff_channels(int c, int cs, int vec) {
+  const int ce = (int)tdg_round_up(c, vec);
+  return (cs % vec == 0 && ce <= cs) ? ce : 0;
+}
 
 struct BwdClassPlan {
   int ntaps, nh, nw;
@@ -1129,6 +1156,7 @@ static void fill_epilogue(IgArgs& a, const TdgEpilogue* epi) {
   a.leak = epi ? epi->leak : 0.f;
   a.mask_mode = epi ? epi->mask_mode : TDG_MASK_NONE;
   a.mask_src = epi ? epi->mask_src : nullptr;
+  a.accumulate = epi ? epi->accumulate : 0;
   if (a.mask_mode == TDG_MASK_NONE) a.mask_src = nullptr;
 }
 
@@ -1143,6 +1171,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   const int ce = eff_channels(d->c, d->cs, vec);
   const bool veca = ce != 0;
   const int C = veca ? ce : d->c;
+  TDG_CHECK_ARG(!veca || ((uintptr_t)x & 15) == 0, "tdg_conv2d_fwd: x must be 16-byte aligned (channel stride allows the vector gather)");
   IgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x;
@@ -1186,6 +1215,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
   const int ke = eff_channels(d->k, d->ks, vec);
   const bool veca = ke != 0;
   const int C = veca ? ke : d->k;
+  TDG_CHECK_ARG(!veca || ((uintptr_t)y & 15) == 0, "tdg_conv2d_bwd_data: y must be 16-byte aligned (channel stride allows the vector gather)");
   IgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = y;
@@ -1271,6 +1301,7 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
   const int C = veca ? ce : d->c;
   // the dense operand (small side) is always read with 16-byte vectors
   TDG_CHECK_ARG(d->ks % vec == 0, "tdg_conv2d_bwd_filter: small-side channel stride %d not a multiple of %d", d->ks, vec);
+  TDG_CHECK_ARG(((uintptr_t)y & 15) == 0 && (!veca || ((uintptr_t)x & 15) == 0), "tdg_conv2d_bwd_filter: operands must be 16-byte aligned");
   WgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x;

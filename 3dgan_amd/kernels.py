@@ -62,6 +62,12 @@ class Act:
     def like(self):
         return Act(self.n, self.h, self.w, self.c, self.dtype, self.buf.device, self.cs)
 
+    def window(self, c_off, c):
+        """Channels [c_off, c_off + c) of every pixel as an Act sharing storage (zero-copy concat:
+        producers write their half of a skip-concatenated tensor in place)."""
+        assert c_off + c <= self.cs
+        return Act(self.n, self.h, self.w, c, self.dtype, self.buf.device, self.cs, self.buf[c_off:])
+
     # host <-> device helpers (tests / checkpoints only)
     def set(self, array):
         t = torch.as_tensor(array, dtype=torch.float32).reshape(self.n, self.h, self.w, self.c)
@@ -81,8 +87,9 @@ def conv_desc(big, small, kh, kw, stride, pad_t, pad_l):
                     kh, kw, stride, pad_t, pad_l, big.dtype)
 
 
-def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=None):
+def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=None, accumulate=False):
     e = Epilogue()
+    e.accumulate = 1 if accumulate else 0
     e.bias = bias.data_ptr() if bias is not None else None
     e.act, e.leak, e.mask_mode = act, leak, mask_mode
     e.mask_src = mask_src if isinstance(mask_src, int) or mask_src is None else mask_src.value
@@ -197,7 +204,7 @@ def bn_fwd(ws, u, c, beta, act, pre, h, stats, rows=None, leak=0.2, eps=1e-3, u_
     need = lib.tdg_bn_workspace_bytes(rows, c)
     w = ws.ensure(need)
     _lib.call('tdg_bn_fwd', u.dtype, u_ptr or u.ptr(), rows, c, u.cs, ptr(beta), eps, act, leak,
-              pre_ptr or pre.ptr(), h_ptr or h.ptr(), ptr(stats), ptr(w), w.numel(), stream())
+              pre_ptr or pre.ptr(), h_ptr or h.ptr(), h.cs, ptr(stats), ptr(w), w.numel(), stream())
 
 
 def bn_bwd(ws, dh, pre, c, beta, stats, act, du, dbeta, rows=None, leak=0.2, beta_acc=0.0,
@@ -206,7 +213,7 @@ def bn_bwd(ws, dh, pre, c, beta, stats, act, du, dbeta, rows=None, leak=0.2, bet
     lib = _lib.load()
     need = lib.tdg_bn_workspace_bytes(rows, c)
     w = ws.ensure(need)
-    _lib.call('tdg_bn_bwd', dh.dtype, dh_ptr or dh.ptr(), pre_ptr or pre.ptr(), rows, c, dh.cs, ptr(beta), ptr(stats),
+    _lib.call('tdg_bn_bwd', dh.dtype, dh_ptr or dh.ptr(), dh.cs, pre_ptr or pre.ptr(), rows, c, pre.cs, ptr(beta), ptr(stats),
               act, leak, du_ptr or du.ptr(), ptr(dbeta), beta_acc, ptr(w), w.numel(), stream())
 
 

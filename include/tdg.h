@@ -70,6 +70,7 @@ typedef struct TdgEpilogue {
   float leak;               /* lrelu leak                                    */
   int32_t mask_mode;        /* TDG_MASK_*                                    */
   const void* mask_src;     /* tensor with the geometry of the output, dtype = desc.dtype */
+  int32_t accumulate;       /* 1: out = (act(acc + bias) + out) * mask  -- sums a second gradient path (U-Net skips) */
 } TdgEpilogue;
 
 const char* tdg_last_error(void);
@@ -121,14 +122,15 @@ size_t tdg_colsum_workspace_bytes(int rows, int cols);
 /* ---- batch norm, training mode, no gamma (tf.contrib.layers.batch_norm defaults,
  *      ops/layers.py:58,103,144) ------------------------------------------
  * fwd : pre = (u - mean) * rsqrt(var + eps) + beta ; h = act(pre)   (u over `rows` x c)
- *       stats[0:c] = mean, stats[c:2c] = rstd (saved for backward)
+ *       stats[0:c] = mean, stats[c:2c] = rstd (saved for backward).  u/pre use channel stride cs, h uses
+ *       h_cs (h may be a channel window of a wider concat buffer); likewise dh uses dh_cs in bwd.
  * bwd : dpre = dh * act'(pre); du = rstd * (dpre - mean(dpre) - xhat * mean(dpre*xhat));
  *       dbeta = beta_acc*dbeta + sum(dpre)                                                */
 size_t tdg_bn_workspace_bytes(int rows, int c);
 int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps,
-               int act, float leak, void* pre, void* h, float* stats, void* workspace,
+               int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
                size_t workspace_bytes, void* stream);
-int tdg_bn_bwd(int dtype, const void* dh, const void* pre, int rows, int c, int cs,
+int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre, int rows, int c, int cs,
                const float* beta, const float* stats, int act, float leak, void* du, float* dbeta,
                float beta_acc, void* workspace, size_t workspace_bytes, void* stream);
 
