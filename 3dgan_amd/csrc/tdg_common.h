@@ -91,6 +91,17 @@ __device__ __forceinline__ float mask_factor(float m, int mode, float leak) {
   return 1.f;
 }
 
+// d act(pre) / d pre evaluated from the pre-activation value (batch-norm backward)
+__device__ __forceinline__ float act_deriv_from_pre(float pre, int act, float leak) {
+  switch (act) {
+    case TDG_ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+    case TDG_ACT_LRELU: return pre > 0.f ? 1.f : leak;
+    case TDG_ACT_TANH: { const float t = tanhf(pre); return 1.f - t * t; }
+    case TDG_ACT_SIGMOID: { const float s = 1.f / (1.f + expf(-pre)); return s * (1.f - s); }
+    default: return 1.f;
+  }
+}
+
 // ---------------------------------------------------------------------------- XCD-aware block remap
 // Blocks b and b+8 share an XCD (round-robin dispatch); give each XCD a contiguous chunk of
 // logical tile ids so that tiles sharing operand panels hit the same L2.  Bijective for any n.

@@ -142,8 +142,7 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
         load_vw<T, VW>(y + i, pre);
 #pragma unroll
         for (int e = 0; e < VW; ++e) {
-          const float dpre = v[e] * (a.act == TDG_ACT_RELU ? (pre[e] > 0.f ? 1.f : 0.f)
-                                     : a.act == TDG_ACT_LRELU ? (pre[e] > 0.f ? 1.f : a.leak) : 1.f);
+          const float dpre = v[e] * act_deriv_from_pre(pre[e], a.act, a.leak);
           s0[e] += dpre; s1[e] += dpre * (pre[e] - bta[e]);
         }
       } else if (MODE == COL_SUM) {
@@ -267,7 +266,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, cons
     load_vw<T, VW>(pre + i, p);
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
-      const float f = act == TDG_ACT_RELU ? (p[e] > 0.f ? 1.f : 0.f) : act == TDG_ACT_LRELU ? (p[e] > 0.f ? 1.f : leak) : 1.f;
+      const float f = act_deriv_from_pre(p[e], act, leak);
       o[e] = rstd[e] * (d[e] * f - m0[e] - (p[e] - b[e]) * m1[e]);
     }
     store_vw<T, VW>(du + i, o);
@@ -636,6 +635,79 @@ extern "C" int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, 
   hipLaunchKernelGGL(gan_logloss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d_real, d_fake, n, seed_real, seed_fake_d,
                      seed_fake_g, scal);
   TDG_HIP_LAUNCH_CHECK("gan_logloss");
+  return TDG_OK;
+}
+
+// ---- pix2pix losses ----------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) p2p_xent_kernel(const T* __restrict__ z, int rows, int cs, int mode, T* __restrict__ seed,
+                                                      float* __restrict__ scal) {
+  __shared__ float sh[4];
+  float dr = 0.f, df = 0.f, gf = 0.f;
+  const float inv = 1.f / (float)rows;
+  for (int i = threadIdx.x; i < rows; i += 256) {
+    const float zr = to_f32<T>(z[(size_t)i * cs]), zf = to_f32<T>(z[(size_t)(rows + i) * cs]);
+    const float sr = log1pf(expf(-fabsf(zr))), sf = log1pf(expf(-fabsf(zf)));
+    dr += fmaxf(zr, 0.f) - zr + sr;
+    df += fmaxf(zf, 0.f) + sf;
+    gf += fmaxf(zf, 0.f) - zf + sf;
+    if (mode) {
+      const float pr = 1.f / (1.f + expf(-zr)), pf = 1.f / (1.f + expf(-zf));
+      seed[(size_t)i * cs] = from_f32<T>(mode == 1 ? (pr - 1.f) * inv : 0.f);
+      seed[(size_t)(rows + i) * cs] = from_f32<T>(mode == 1 ? pf * inv : (pf - 1.f) * inv);
+    }
+  }
+  dr = block_sum256(dr, sh);
+  df = block_sum256(df, sh);
+  gf = block_sum256(gf, sh);
+  if (threadIdx.x == 0) { scal[0] = dr * inv; scal[1] = df * inv; scal[2] = gf * inv; }
+}
+extern "C" int tdg_p2p_xent(int dtype, const void* logits, int rows, int cs, int mode, void* seed, float* scal, void* stream) {
+  TDG_CHECK_ARG(logits && scal && rows > 0 && cs > 0 && (mode == 0 || seed), "tdg_p2p_xent: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(p2p_xent_kernel<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(logits), rows, cs,
+                       mode, static_cast<T*>(seed), scal);
+  })
+  TDG_HIP_LAUNCH_CHECK("p2p_xent");
+  return TDG_OK;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) p2p_l1_kernel(const T* __restrict__ y, const T* __restrict__ g, int rows, int cs, float wgt,
+                                                    T* __restrict__ dg, int dgs, float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float a = 0.f, q = 0.f;
+  const float inv = 1.f / (float)rows;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < rows; i += gridDim.x * 256) {
+    const float d = 0.5f * (to_f32<T>(g[(size_t)i * cs]) - to_f32<T>(y[(size_t)i * cs]));   // g01 - y01
+    a += fabsf(d);
+    q += d * d;
+    if (dg) {
+      const float s = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      dg[(size_t)i * dgs] = from_f32<T>(to_f32<T>(dg[(size_t)i * dgs]) + wgt * 0.5f * s * inv);
+    }
+  }
+  a = block_sum256(a, sh);
+  q = block_sum256(q, sh);
+  if (threadIdx.x == 0) { partial[blockIdx.x] = a; partial[RED_BLOCKS + blockIdx.x] = q; }
+}
+__global__ void __launch_bounds__(256) p2p_l1_final_kernel(const float* __restrict__ partial, int rows, float* __restrict__ scal) {
+  __shared__ float sh[4];
+  float a = 0.f, q = 0.f;
+  for (int i = threadIdx.x; i < RED_BLOCKS; i += 256) { a += partial[i]; q += partial[RED_BLOCKS + i]; }
+  a = block_sum256(a, sh);
+  q = block_sum256(q, sh);
+  if (threadIdx.x == 0) { scal[0] = a / (float)rows; scal[1] = sqrtf(q / (float)rows); }
+}
+extern "C" int tdg_p2p_l1(int dtype, const void* y, const void* g, int rows, int cs, float weight, void* dg, int dgs, float* scal,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(y && g && scal && workspace && rows > 0 && cs > 0, "tdg_p2p_l1: bad argument");
+  if (workspace_bytes < 2 * RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_p2p_l1: workspace too small"); return TDG_EWORKSPACE; }
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(p2p_l1_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(y),
+                       static_cast<const T*>(g), rows, cs, weight, static_cast<T*>(dg), dgs, static_cast<float*>(workspace));
+  })
+  hipLaunchKernelGGL(p2p_l1_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace), rows, scal);
+  TDG_HIP_LAUNCH_CHECK("p2p_l1");
   return TDG_OK;
 }
 

@@ -6,3 +6,10 @@ def model_funcs():
     from .gan import gan
     from .vae import vae
     return {'gan': gan, 'wgan': gan, 'iwgan': gan, 'vae': vae}
+
+
+def get_model(name):
+    """hem/models/ModelPlugin.py:4-8: plugin lookup by `name`."""
+    from .pix2pix import pix2pix
+    plugins = {pix2pix.name: pix2pix}
+    return plugins[name]

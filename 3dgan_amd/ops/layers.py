@@ -43,8 +43,9 @@ def add_arg_scope(func):
 # ------------------------------------------------------------------------------ nets / scopes
 class LayerSpec:
     def __init__(self, kind, name, in_size, out_size, k=1, stride=1, use_bn=False, act=None,
-                 in_shape=None, out_shape=None, padding='SAME', init='xavier'):
+                 in_shape=None, out_shape=None, padding='SAME', init='xavier', dropout=0):
         self.kind, self.name = kind, name
+        self.dropout = dropout
         self.in_size, self.out_size, self.k, self.stride = in_size, out_size, k, stride
         self.use_bn, self.act = use_bn, act
         self.in_shape, self.out_shape = in_shape, out_shape
@@ -121,6 +122,8 @@ def reset_graph():
 def variable_scope(name):
     """tf.variable_scope(name): selects (or creates) the Net that collects the layers.
     Entering the same scope again starts a new pass over the same variables."""
+    if _scope_stack:                                   # nested scopes join their names, as in TF
+        name = _scope_stack[-1].name + '/' + name
     net = _nets.get(name)
     if net is None:
         net = _nets[name] = Net(name)
@@ -179,6 +182,25 @@ def flatten(x, name=None):
     return reshape(x, [-1, n])
 
 
+def _reject_unsupported(name, dropout, renorm, instance_norm):
+    if dropout:
+        raise NotImplementedError('layer %s: dropout > 0 is not available in this build (SURVEY.md section 2 row 12)' % name)
+    if renorm or instance_norm:
+        raise NotImplementedError('layer %s: batch-renorm / instance-norm are out of scope (thesis samplers only)' % name)
+
+
+def concat(xs, axis=-1):
+    """tf.concat along channels (axis=1 in the reference's NCHW == last axis in NHWC).  Executed as a
+    zero-copy concat: producers write their channel window of one buffer (models/pix2pix.py)."""
+    base = xs[0].shape[:-1]
+    for t in xs:
+        if t.shape[:-1] != base:
+            raise ValueError('concat: spatial shapes differ: %s' % [t.shape for t in xs])
+    out = Sym(base + (sum(t.shape[-1] for t in xs),), producer=None, source='concat')
+    out.parts = list(xs)
+    return out
+
+
 def _same(in_size, k, stride):
     return -(-in_size // stride)
 
@@ -198,8 +220,10 @@ def dense(x, input_size, output_size, init='xavier', use_batch_norm=False, activ
 
 @add_arg_scope
 def conv2d(x, input_size, output_size, filter_size=3, stride=1, init='xavier', use_batch_norm=False,
-           activation=None, reuse=False, name=None, padding='SAME'):
-    """ops/layers.py:66-107: tf.nn.conv2d SAME + bias [+ batch_norm] [+ activation]."""
+           activation=None, reuse=False, name=None, padding='SAME', dropout=0, use_batch_renorm=False,
+           use_instance_norm=False):
+    """ops/layers.py:66-107 (gen-2: hem/ops/layers.py:70-135): tf.nn.conv2d + bias [+ batch_norm] [+ activation]."""
+    _reject_unsupported(name, dropout, use_batch_renorm, use_instance_norm)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('conv2d %s: input has %d channels, expected %d' % (name, c, input_size))
@@ -215,8 +239,12 @@ def conv2d(x, input_size, output_size, filter_size=3, stride=1, init='xavier', u
 
 @add_arg_scope
 def deconv2d(x, input_size, output_size, filter_size=3, stride=2, init='xavier', use_batch_norm=False,
-             activation=None, reuse=False, name=None):
-    """ops/layers.py:111-148: tf.nn.conv2d_transpose SAME, output_shape = 2 x input (:140-141)."""
+             activation=None, reuse=False, name=None, output_shape=None, dropout=0, use_batch_renorm=False,
+             use_instance_norm=False, padding='SAME'):
+    """ops/layers.py:111-148 (gen-2: hem/ops/layers.py:138-211): tf.nn.conv2d_transpose SAME, output = 2 x input."""
+    _reject_unsupported(name, dropout, use_batch_renorm, use_instance_norm)
+    if output_shape is not None or padding != 'SAME':
+        raise NotImplementedError('deconv2d %s: explicit output_shape / VALID padding are only used by the thesis models' % name)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('deconv2d %s: input has %d channels, expected %d' % (name, c, input_size))

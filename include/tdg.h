@@ -162,6 +162,18 @@ int tdg_mean_f32(const float* x, int n, float* out, void* stream);
  *   seed_real = d d_loss/d logit_real, seed_fake_d = d d_loss/d logit_fake, seed_fake_g = d g_loss/d logit_fake */
 int tdg_gan_logloss(const float* d_real, const float* d_fake, int n, float* seed_real, float* seed_fake_d,
                     float* seed_fake_g, float* scal, void* stream);
+/* ---- pix2pix losses (hem/models/pix2pix.py:263-304) -------------------------------------------------
+ * Sigmoid cross-entropy terms on the PatchGAN logits (channel 0, row stride cs) of the real pass
+ * (rows [0, rows)) and the fake pass (rows [rows, 2*rows)):
+ *   scal[0] = d_real = mean xent(z_real, 1), scal[1] = d_fake = mean xent(z_fake, 0),
+ *   scal[2] = g_fake = mean xent(z_fake, 1)      (xent(z,l) = max(z,0) - z*l + log(1+exp(-|z|)), App. A-7)
+ * mode 1 (D step): seed = d(d_real + d_fake)/dz for both passes; mode 2 (G step): seed_fake = d g_fake/dz,
+ * seed_real = 0; mode 0: losses only.  seed has the layout of logits. */
+int tdg_p2p_xent(int dtype, const void* logits, int rows, int cs, int mode, void* seed, float* scal, void* stream);
+/* y, g: channel 0 of [-1,1] tensors with row stride cs.  scal[0] = l1 = mean|y01 - g01|, scal[1] = rmse (:285,299,
+ * hem/ops/losses.py:10-11) after rescaling both to [0,1].  If dg != NULL: dg[r*dgs] += weight * d l1 / d g. */
+int tdg_p2p_l1(int dtype, const void* y, const void* g, int rows, int cs, float weight, void* dg, int dgs, float* scal,
+               void* workspace, size_t workspace_bytes, void* stream);
 /* ---- VAE pieces (models/vae.py:66-90,113-129) -------------------------------------------------------
  * heads = [z_mean | z_stddev] rows of 2L (channel stride hs); z = mean + stddev * eps (models/vae.py:128) */
 int tdg_vae_reparam(int dtype, const void* heads, int hs, const void* eps, int es, int rows, int L, void* z, int zs,

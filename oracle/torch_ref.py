@@ -27,7 +27,7 @@ def conv2d_same(x, K, stride):
     _, pt, pb = same_pad(h, kh, stride)
     _, pl, pr = same_pad(w, kw, stride)
     xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
-    y = F.conv2d(xn, K.permute(3, 2, 0, 1), stride=stride)
+    y = F.conv2d(xn, K.permute(3, 2, 0, 1).contiguous(), stride=stride)
     return y.permute(0, 2, 3, 1)
 
 
@@ -39,7 +39,7 @@ def conv2d_transpose_same(x, K, stride=2):
     H, W = h * stride, w * stride
     _, pt, pb = same_pad(H, kh, stride)
     _, pl, pr = same_pad(W, kw, stride)
-    full = F.conv_transpose2d(x.permute(0, 3, 1, 2), K.permute(3, 2, 0, 1), stride=stride)
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2).contiguous(), K.permute(3, 2, 0, 1).contiguous(), stride=stride)
     # full size = (h-1)*stride + kh ; padded forward input size = H + pt + pb >= that
     fh, fw = full.shape[2], full.shape[3]
     full = F.pad(full, (0, W + pl + pr - fw, 0, H + pt + pb - fh))
