@@ -45,3 +45,19 @@ class ArraySource:
         idx = slice(self.i, self.i + self.B)
         self.i += self.B
         return (self.data[self.perm[idx]] if self.perm is not None else self.data[idx]).contiguous()
+
+
+class SyntheticPairSource:
+    """(rgb, depth) pairs for pix2pix: x ~ U[0,1) [B,256,256,3], y ~ U(0,1) exclusive of
+    exact 0/1 [B,256,256,1] (the nyuv2 plugin drops depth maps containing 0 or 1, hem/data/nyuv2.py:258-266)."""
+
+    def __init__(self, n_batches, batch_size, device, size=256, seed=1234, rank=0):
+        g = torch.Generator(device='cpu').manual_seed(seed + 7919 * rank)
+        self.x = torch.rand(n_batches, batch_size, size, size, 3, generator=g).to(device)
+        self.y = (torch.rand(n_batches, batch_size, size, size, 1, generator=g) * 0.98 + 0.01).to(device)
+        self.i = 0
+
+    def next_batch(self):
+        k = self.i % self.x.shape[0]
+        self.i += 1
+        return self.x[k], self.y[k]

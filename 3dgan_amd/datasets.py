@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from . import tfrecord
-from .data import ArraySource, SyntheticSource
+from .data import ArraySource, SyntheticSource, SyntheticPairSource
 
 
 def _cifar(data_dir):
@@ -50,6 +50,8 @@ def _mnist(data_dir):
 
 def get_dataset(args, sess):
     name, B = args.dataset, args.batch_size
+    if name == 'synthetic' and args.model == 'pix2pix':
+        return SyntheticPairSource(4, B, sess.device, 256, 1234, sess.rank), 4 * B * sess.world_size, (256, 256, 3)
     if name == 'synthetic':
         shape = (32, 32, 3)
         if args.resize:

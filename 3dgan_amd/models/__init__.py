@@ -5,7 +5,16 @@ def model_funcs():
     """The dispatch table of train.py:240-244."""
     from .gan import gan
     from .vae import vae
-    return {'gan': gan, 'wgan': gan, 'iwgan': gan, 'vae': vae}
+
+    def pix2pix_func(x, args, sess=None):
+        """gen-2 plugins expose .train(sess, args, feed_dict); adapt to the gen-1 train_func contract."""
+        model = get_model('pix2pix')(x, args, sess)
+
+        def train_func(sess_=None, args_=None):
+            return model.train(sess_, args_, None)
+        train_func.replica = model
+        return train_func
+    return {'gan': gan, 'wgan': gan, 'iwgan': gan, 'vae': vae, 'pix2pix': pix2pix_func}
 
 
 def get_model(name):

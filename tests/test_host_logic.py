@@ -92,7 +92,9 @@ def test_cli_defaults_alias_and_config_file(tmp_path):
     train = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(train)
     p = train.build_parser()
-    a = p.parse_args([])
+    a = train.resolve_defaults(p.parse_args([]))
+    assert train.resolve_defaults(p.parse_args(['--model', 'pix2pix'])).n_disc_train == 1
+    assert train.resolve_defaults(p.parse_args(['--model', 'pix2pix', '--n_disc_train', '3'])).n_disc_train == 3
     # train.py:62-182 defaults
     assert (a.n_gpus, a.batch_size, a.n_disc_train, a.optimizer, a.lr, a.momentum, a.decay) == (1, 256, 5, 'rmsprop', 0.001, 0.01, 0.9)
     assert (a.beta1, a.beta2, a.latent_size, a.dataset, a.epochs, a.buffer_size) == (0.9, 0.999, 200, 'floorplans', '3', 10000)

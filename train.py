@@ -66,7 +66,8 @@ def build_parser():
     add('--epoch_size', type=int, default=-1, help='Iterations per epoch; default: the whole dataset.')
     add('--examples', type=int, default=64, help='Number of examples to generate when sampling.')
     add('--dir', type=str, default='workspace/{}'.format(uuid.uuid4()), help='Checkpoints, logs; resumes if populated.')
-    add('--n_disc_train', type=int, default=5, help='Discriminator steps per generator step.')
+    add('--n_disc_train', type=int, default=None,
+        help='Discriminator steps per generator step (default 5; 1 for --model pix2pix, its plugin default).')
     add = optimizer_args.add_argument
     add('--optimizer', type=lambda s: s.lower(), default='rmsprop')
     add('--lr', type=float, default=0.001)
@@ -77,7 +78,7 @@ def build_parser():
     add('--beta1', type=float, default=0.9)
     add('--beta2', type=float, default=0.999)
     add = model_args.add_argument
-    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan (vae, pix2pix: see DESIGN.md).')
+    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan | vae | pix2pix.')
     add('--latent_size', type=int, default=200)
     add = data_args.add_argument
     add('--dataset', '--data', dest='dataset', type=lambda s: s.lower(), default='floorplans',
@@ -88,7 +89,23 @@ def build_parser():
     add('--grayscale', default=False, action='store_true')
     add('--cache_dir', default=None)
     add('--data_dir', default='data', help='Where the dataset files live.')
+    # gen-2 plugin flags of --model pix2pix (hem/models/pix2pix.py:36-78, merged by hem/util/arguments.py:153-163)
+    p2p = parser.add_argument_group('pix2pix')
+    p2p.add_argument('--skip_layers', action='store_true', default=False, help='Accepted; skips are always on in the reference.')
+    p2p.add_argument('--noise', type=str, nargs='*', choices=['input', 'latent', 'end'], default=[])
+    p2p.add_argument('--dropout', type=float, default=0)
+    p2p.add_argument('--batch_norm_disc', action='store_true', default=False)
+    p2p.add_argument('--batch_norm_gen', action='store_true', default=False)
+    p2p.add_argument('--add_l1', action='store_true', default=False)
+    p2p.add_argument('--lambda', type=float, default=10.0, help='Ignored, as in the reference (L1 weight is 10.0).')
     return parser
+
+
+def resolve_defaults(args):
+    """train.py:107-111 default 5; the pix2pix plugin overrides it to 1 (hem/models/pix2pix.py:65-68)."""
+    if args.n_disc_train is None:
+        args.n_disc_train = 1 if args.model == 'pix2pix' else 5
+    return args
 
 
 def message(s):
@@ -119,6 +136,7 @@ def main(argv=None):
     parser = build_parser()
     args = parser.parse_args(argv)
     maybe_relaunch(args, argv)
+    resolve_defaults(args)
     if args.n_gpus < 1:
         raise SystemExit('--n_gpus 0: this build has no CPU path (the reference raises NameError here, SURVEY App. C-8)')
 
