@@ -508,14 +508,72 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns pixel r16 x 4 consecutive channels per 16x16 tile; vector path only
-  //      (the launcher guarantees N % 4 == 0 and Cso % 4 == 0) ------------------------------------------
+  // ---- epilogue ---------------------------------------------------------------------------------------
   const int N = args.N, Cso = args.Cso;
   T* out = static_cast<T*>(args.out);
   const T* msk = static_cast<const T*>(args.mask_src);
   const float* bias = args.bias;
   const int act = args.act, mmode = args.mask_mode, accum = args.accumulate;
   const float leak = args.leak;
+
+  if constexpr (sizeof(T) == 2) {
+    // bf16: stage the tile through the (now idle) LDS ring so that global stores (and mask loads) are whole
+    // 16-byte chunks of contiguous pixel rows instead of 8-byte pieces scattered over 16 pixels per instruction
+    if (!accum && (N & 7) == 0) {
+      constexpr int PE = BN * 2 + 16;                          // row pitch: +16 B keeps the 8-byte writes spread over banks
+      constexpr int CPR = BN * 2 / 16;                         // 16-byte chunks per row
+      static_assert(BM * PE + BM * 8 <= 2 * STAGE, "epilogue staging must fit the ring");
+      char* sE = smem;
+      long long* sPix = reinterpret_cast<long long*>(smem + BM * PE);
+      if (tid < BM) {
+        const int m = m0 + tid;
+        long long p = -1;
+        if (m < M) {
+          const unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
+          const unsigned rem = (unsigned)m - nb * (unsigned)(cl.GH * cl.GW);
+          const unsigned a = fd_div(rem, cl.fd_gw);
+          const unsigned b = rem - a * (unsigned)cl.GW;
+          p = (long long)(((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
+                           b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)Cso);
+        }
+        sPix[tid] = p;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (wn * TN + j) * 16 + q * 4;
+        const int n = n0 + col;
+        if (j < tnw) {
+          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+          if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            f32x4 v = acc[i][j] + bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, leak);
+            *reinterpret_cast<bf16x4*>(sE + (wm * WMR + i * 16 + r16) * PE + col * 2) =
+                bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          }
+        }
+      }
+      __syncthreads();
+      for (int c = tid; c < BM * CPR; c += 512) {
+        const int row = c / CPR, cc = c - row * CPR;
+        const long long p = sPix[row];
+        const int n = n0 + cc * 8;
+        if (p < 0 || n >= N) continue;
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
+        if (mmode != TDG_MASK_NONE) {
+          const bf16x8 mv = *reinterpret_cast<const bf16x8*>(msk + p + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], mmode, leak));
+        }
+        *reinterpret_cast<bf16x8*>(out + p + n) = v;
+      }
+      return;
+    }
+  }
+
+  // direct form (f32 tiles, accumulating epilogues, N not a multiple of 8): lane owns pixel r16 x 4 channels
   size_t pix[TM];
   bool okm[TM];
 #pragma unroll
@@ -936,14 +994,15 @@ template <typename T>
 int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   constexpr int BM = 128;
   static const int dbg = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
-  const char* dma_env = getenv("TDG_DMA");          // diagnostics: 0 = never, 2 = whenever legal, default = by size
+  const char* dma_env = getenv("TDG_DMA");          // diagnostics: 0 = never, 3 / 4 = force the 192 / 256-row tile
   const int dma_mode = dma_env ? atoi(dma_env) : 1;
   a.debug = dbg;
   int mmax = 0;
   for (int c = 0; c < a.nclasses; ++c) mmax = a.cls[c].M > mmax ? a.cls[c].M : mmax;
   // large problems: 256-row tiles fed by LDS-DMA (needs >= ~1 workgroup per CU to pay off)
-  if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0 &&
-      (dma_mode >= 2 || (long long)tdg_ceil_div(mmax, 256) * tdg_ceil_div(a.N, 208) * a.nclasses >= 192)) {
+  // 208-column problems with a vector gather always take the LDS-DMA kernel (measured faster than the
+  // register-staged one even when the grid does not fill the chip)
+  if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
     // one 8-wave workgroup per CU: pick the row tile whose workgroup count wastes less of the last round
     const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
     const long long t256 = per * tdg_ceil_div(mmax, 256), t192 = per * tdg_ceil_div(mmax, 192);
