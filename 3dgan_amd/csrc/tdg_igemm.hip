@@ -876,6 +876,181 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const WgArgs args) 
   }
 }
 
+// ============================================================================================
+// Large filter gradients (bf16): 256 (filter rows) x 208 (columns) tile, 8 waves as 4 x 2, both
+// operand slabs (64 pixel rows per step) streamed by LDS-DMA into a 2-stage ring, one barrier per
+// step.  Slab rows are 512 bytes (256 kk / 224+32 n); chunk c of row r sits at physical chunk
+// c ^ 2*f(r), f(r) = (r & 3) | (((r >> 3) & 1) << 2): conflict-free for the transposing
+// ds_read_b64_tr_b16 fragment reads, and -- with DMA instructions dealt to waves by bits 0 and 2 of
+// their index -- a per-lane constant, so each lane's (tap, channel) / column never changes.
+// ============================================================================================
+#define WD_MR 64
+#define WD_ROWB 512
+__device__ __forceinline__ int wd_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <int TK, int TN, int t, typename FragFn>
+__device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2][TK], bf16x8 (&fg)[2 * TN], const char* sA,
+                                            const char* sG, int wk, int wn, FragFn& frag) {
+  constexpr int NT = 2 * TN;
+  if constexpr (t < NT) {
+    constexpr int ks = t / TN, j = t - ks * TN;
+    if constexpr (t + 1 < NT) {
+      constexpr int ks1 = (t + 1) / TN, j1 = (t + 1) - ks1 * TN;
+      fg[t + 1] = frag(sG, ks1, (wn * TN + j1) * 16);
+    }
+    if constexpr (t < TK) fa[1][t] = frag(sA, 1, wk * 64 + t * 16);
+#pragma unroll
+    for (int i = 0; i < TK; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[t], fa[ks][i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((t + 1 < NT ? 1 : 0) + (t < TK ? 1 : 0)), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
+    wd_mma_tile<TK, TN, t + 1>(acc, fa, fg, sA, sG, wk, wn, frag);
+  }
+}
+
+template <int BN>
+__global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs args) {
+  using T = bf16_t;
+  constexpr int BKK = 256, VEC = 8;
+  constexpr int TK = 4, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
+  constexpr int SLAB = WD_MR * WD_ROWB;              // 32 KB per operand per stage
+  constexpr int STAGE = 2 * SLAB;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) bf16x4* lds_b4_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  int* sTap = reinterpret_cast<int*>(smem + 2 * STAGE);
+
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_k = bid / args.ntiles_n;
+  const int tile_n = bid - tile_k * args.ntiles_n;
+  const int kk0 = tile_k * BKK, n0 = tile_n * BN;
+  const int split = blockIdx.z;
+  const int m_begin = split * args.m_per_split;
+  const int m_end = min(args.M, m_begin + args.m_per_split);
+  const int SH = args.SH, SW = args.SW, Cs = args.Cs, sigma = args.sigma, Gs = args.Gs, GHW = args.GH * args.GW, GW = args.GW;
+
+  if (tid < IG_MAX_TAPS) sTap[tid] = args.tap[tid];
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
+  const __amdgpu_buffer_rsrc_t rG = make_rsrc(args.g, args.g_bytes);
+
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int hrow = lane >> 5;                                   // row inside a 2-row DMA instruction
+  const int b0 = wave & 1, b2 = (wave >> 1) & 1, b4 = (wave >> 2) & 1;
+  const int lch = (lane & 31) ^ (2 * ((2 * b0 + hrow) | (b2 << 2)));   // this lane's logical 16-byte chunk (0..31)
+
+  // A: (tap, channel vector) of this lane's chunk -- fixed for the whole kernel
+  int a_dh = 0, a_dw = 0, a_koff = 0;
+  bool a_kok;
+  {
+    const int kv = (kk0 >> 3) + lch;
+    const int CV = (int)args.fd_c.d;
+    const int tap = (int)fd_div((unsigned)kv, args.fd_c);
+    const int cv = kv - tap * CV;
+    a_kok = tap < args.ntaps;
+    const int pk = sTap[a_kok ? tap : 0];
+    a_dh = tap_dh(pk);
+    a_dw = tap_dw(pk);
+    a_koff = (a_dh * SW + a_dw) * Cs + cv * VEC;
+  }
+  const int g_n = n0 + lch * VEC;
+  const bool g_nok = (lch * VEC < TN * 32) && (g_n < args.N);
+
+  auto issue = [&](int mstep, int stage) {
+    char* sA = smem + stage * STAGE;
+    char* sG = sA + SLAB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int I = b0 | ((j & 1) << 1) | (b2 << 2) | ((j >> 1) << 3) | (b4 << 4);
+      const int m = mstep + 2 * I + hrow;
+      const int okm = m < m_end;
+      const unsigned mm = okm ? (unsigned)m : 0u;
+      const unsigned nb = fd_div(mm, args.fd_ghw);
+      const unsigned rem = mm - nb * (unsigned)GHW;
+      const unsigned a = fd_div(rem, args.fd_gw);
+      const unsigned b = rem - a * (unsigned)GW;
+      const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
+      const int ok = okm & (int)a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+      const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
+      const unsigned offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(sA + I * 1024), 16, offa, 0, 0, 0);
+      const unsigned offg = (okm & (int)g_nok) ? ((unsigned)m * (unsigned)Gs + (unsigned)g_n) * 2u : OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (lds_ptr_t)(sG + I * 1024), 16, offg, 0, 0, 0);
+    }
+  };
+
+  const int r16 = lane & 15, q = lane >> 4;
+  const int wk = wave & 3, wn = wave >> 2;
+  const int tnw = wn == 0 ? TN : TN1;
+  // transposing fragment reads: row = ks*32 + 8q + 4h + (r16>>2); 8 bytes at column col0 + (r16&3)*4
+  const int frow = 8 * q + (r16 >> 2);
+  const int fsw = 2 * ((r16 >> 2) | ((q & 1) << 2));             // wd_f of that row (the + 4h / + 32 ks terms do not change it)
+  const int fcol = (r16 & 3) * 4;
+
+  f32x4 acc[TK][TN];
+#pragma unroll
+  for (int i = 0; i < TK; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto frag = [&](const char* slab, int ks, int col0) -> bf16x8 {
+    const int col = col0 + fcol;
+    const int cb = (((col >> 3) ^ fsw) << 4) + ((col & 7) << 1);
+    const char* p = slab + (ks * 32 + frow) * WD_ROWB + cb;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)p);
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)(p + 4 * WD_ROWB));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  };
+
+  issue(m_begin, 0);
+  __syncthreads();
+  int stage = 0;
+  for (int mstep = m_begin; mstep < m_end; mstep += WD_MR) {
+    if (mstep + WD_MR < m_end) issue(mstep + WD_MR, stage ^ 1);
+    const char* sA = smem + stage * STAGE;
+    const char* sG = sA + SLAB;
+    {
+      // software-pipelined: the fragment of column tile t+1 is requested before the MFMAs of tile t
+      bf16x8 fa[2][TK];
+      bf16x8 fg[2 * TN];
+#pragma unroll
+      for (int i = 0; i < TK; ++i) fa[0][i] = frag(sA, 0, wk * 64 + i * 16);
+      fg[0] = frag(sG, 0, (wn * TN) * 16);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 2, 0);
+      wd_mma_tile<TK, TN, 0>(acc, fa, fg, sA, sG, wk, wn, frag);
+    }
+    __syncthreads();
+    stage ^= 1;
+  }
+
+  // ---- epilogue: lane owns filter row kk (r16) x 4 consecutive n ----------------------------------
+  float* slab = args.slabs + (size_t)split * (size_t)args.slab_stride;
+  const int Ceff = (int)args.fd_c.d * VEC;
+#pragma unroll
+  for (int i = 0; i < TK; ++i) {
+    const int kk = kk0 + wk * 64 + i * 16 + r16;
+    if (kk >= args.KK) continue;
+    const int tap = kk / Ceff;
+    const int c = kk - tap * Ceff;
+    if (c >= args.Clog) continue;
+    float* rowp = slab + ((size_t)tap * args.Clog + c) * (size_t)args.Nlog;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 16 + q * 4;
+      if (j >= tnw) continue;
+      if (n + 3 < args.Nlog && (args.Nlog & 3) == 0) {
+        *reinterpret_cast<f32x4*>(rowp + n) = acc[i][j];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < args.Nlog) rowp[n + e] = acc[i][j][e];
+      }
+    }
+  }
+}
+
 // dw[i] = beta*dw[i] + sum_z slabs[z][i]   (fixed summation order: 16 z-lanes, then lane order)
 __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                          size_t n, int nsplit, size_t stride, float beta) {
@@ -1044,6 +1219,20 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
     tdg_note_kernel(names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
   }
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad");
+  return TDG_OK;
+}
+
+int launch_wgrad_dma208(WgArgs& a, hipStream_t s) {
+  const size_t lds = 4 * (size_t)WD_MR * WD_ROWB + IG_MAX_TAPS * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<208>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
+  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<208>), grid, block, lds, s, a);
+  tdg_note_kernel("igemm_wgrad_dma_kernel<bf16,256,208>");
+  TDG_HIP_LAUNCH_CHECK("igemm_wgrad_dma");
   return TDG_OK;
 }
 
@@ -1319,14 +1508,24 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
                               : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
 }
 
+// large bf16 filter gradients take the LDS-DMA kernel (256 x 208 tiles, one workgroup per CU)
+static bool wgrad_use_dma(const TdgConvDesc* d) {
+  const char* e = getenv("TDG_WDMA");                   // diagnostics: 0 disables
+  if (e && atoi(e) == 0) return false;
+  if (d->dtype != TDG_BF16) return false;
+  const int ce = eff_channels(d->c, d->cs, 8);
+  return ce != 0 && pick_bn(d->k) == 208 && (long long)d->kh * d->kw * ce >= 1024;
+}
+
 static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es;
   const int mr = d->dtype == TDG_BF16 ? WgGeom<bf16_t>::MR : WgGeom<float>::MR;
   int ce = eff_channels(d->c, d->cs, vec);
   if (!ce) ce = d->c;
   const int M = n_images * d->oh * d->ow;
-  const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, 128) * tdg_ceil_div(d->k, pick_bn(d->k));
-  int want = tdg_ceil_div(768, tiles);                  // aim for ~3 workgroups per CU
+  const bool dma = wgrad_use_dma(d);
+  const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, dma ? 256 : 128) * tdg_ceil_div(d->k, pick_bn(d->k));
+  int want = dma ? 512 / tiles : tdg_ceil_div(768, tiles);   // DMA: ~2 rounds of one workgroup per CU; else ~3 per CU
   const int max_split = tdg_ceil_div(M, mr * 4);        // keep >= 4 steps per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
@@ -1381,12 +1580,14 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
   a.nsplit = wgrad_nsplit(d, n_images, &a.m_per_split);
   a.slab_stride = tdg_round_up((long long)a.ntaps * d->c * d->k, 4);
   const int bn = pick_bn(d->k);
+  const bool dma = wgrad_use_dma(d);
   a.ntiles_n = tdg_ceil_div(a.N, bn);
-  a.ntiles_k = tdg_ceil_div(a.KK, 128);
+  a.ntiles_k = tdg_ceil_div(a.KK, dma ? 256 : 128);
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
-  rc = d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
-                            : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
+  rc = dma ? launch_wgrad_dma208(a, (hipStream_t)stream)
+           : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
+                                  : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
   const size_t n = (size_t)a.ntaps * d->c * d->k;
   const int blocks = (int)(((n + 3) / 4 + 15) / 16);
