@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib3dgan_hip.so')
+LIB_PATH = os.environ.get('TDG_LIB_PATH') or os.path.join(_HERE, 'lib3dgan_hip.so')   # override: diagnostic builds only
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4

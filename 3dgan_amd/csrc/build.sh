@@ -3,12 +3,14 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../lib3dgan_hip.so
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+EXTRA=""
+if [ "$1" = "stamps" ]; then OUT=../lib3dgan_hip_stamps.so; EXTRA="-DTDG_STAMPS"; fi   # diagnostic build with in-kernel cycle stamps
+FLAGS="$EXTRA --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
 pids=()
 for f in tdg_igemm tdg_elementwise; do
-  hipcc $FLAGS -c $f.hip -o $f.o &
+  hipcc $FLAGS -c $f.hip -o $f$1.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC tdg_igemm.o tdg_elementwise.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC tdg_igemm$1.o tdg_elementwise$1.o -o $OUT
 echo "built $OUT"

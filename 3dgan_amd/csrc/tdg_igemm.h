@@ -18,7 +18,7 @@ struct IgClass {
   int Kp;                // packed filter row pitch (elements) = nsteps * BKE
   int oh0, ow0;
   unsigned w_off_bytes;  // this class's packed filter block inside the packed buffer
-  FastDiv fd_ghw, fd_gw;
+  FastDiv fd_ghw, fd_gw, fd_nw;
   // taps form a grid: tap t = th*nw + tw reads source offset (dh0 + sh*th, dw0 + sw*tw)
   int nh, nw, dh0, dw0, sh, sw;
   short tap[IG_MAX_TAPS];  // (dh & 0xff) | ((dw & 0xff) << 8), signed bytes
@@ -38,6 +38,7 @@ struct IgArgs {
   int act, mask_mode, accumulate;
   float leak;
   int ntiles_n, ntiles_m_max, nclasses;
+  unsigned long long* stamps;  // diagnostic build (-DTDG_STAMPS) only: per-wave cycle sums; null otherwise
   int debug;             // TDG_DEBUG_ABLATE (diagnostics only): 1 no global loads in loop, 2 + no LDS stores, 3 no MFMA
   IgClass cls[IG_MAX_CLASSES];
 };

@@ -23,6 +23,18 @@
 
 #define OOB_OFFSET 0xFFFFFF00u
 
+// In-kernel cycle stamps: compiled only into the diagnostic library (build.sh stamps); no stamp executes in the product build.
+#ifdef TDG_STAMPS
+#define TDG_STAMP(var)                                                                            \
+  do {                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");                  \
+    __builtin_amdgcn_sched_barrier(0);                                                            \
+  } while (0)
+#else
+#define TDG_STAMP(var) do { } while (0)
+#endif
+
 template <typename T>
 struct Mma;
 template <>
@@ -349,14 +361,76 @@ struct TapWalk {
 // x 8 physical chunks, lane l supplies logical chunk (l&7) ^ ((row>>1)&7).  Instructions are dealt
 // to waves by parity of their index so that this XOR term is one constant per lane.
 // ============================================================================================
+// Per-lane state of the LDS-DMA loader of igemm_fwd_dma_kernel.  A K step's loads are NP single
+// wave-instructions ("pieces": NAJ of the gathered operand, NBJ of the packed filter; every wave issues
+// the same number, a wave with one filter piece less issues an out-of-range one into don't-care rows), so
+// that the K loop can place each piece between two MFMA groups instead of stalling on all of them at
+// once: with the pieces in one block the stamps showed 35-43 % of a step spent issuing them (the
+// texture path takes a 1 KiB piece every ~150 cycles with eight waves queueing) and no MFMA running.
+template <typename T, int BM, int BN>
+struct DmaLoader {
+  static constexpr int NAJ = BM / 64;
+  static constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
+  static constexpr int NIB = BNL / 8;
+  static constexpr int NBJ = (NIB + 7) / 8;
+  static constexpr int NP = NAJ + NBJ;
+  static constexpr int VEC = 16 / (int)sizeof(T);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  __amdgpu_buffer_rsrc_t rA, rB;
+  int a_h[NAJ], a_w[NAJ];
+  unsigned a_base[NAJ];
+  unsigned b_row[NBJ];          // byte offset of this lane's chunk at step 0; OOB_OFFSET: row outside N or dummy piece
+  int a_lds[NAJ], b_lds[NBJ];   // wave-uniform byte offsets inside a stage
+  int SH, SW, Cs, CV, nh, nw, dh0, dw0, shh, sww, lch;
+  FastDiv fd_cv, fd_nw;
+  // state of the step being loaded
+  int dh, dw, t_ok;
+  unsigned koff, kbyte;
+
+  // K chunk (step, lch) -> tap (th, tw) and 16-byte vector cv inside the tap's channels
+  __device__ __forceinline__ void prepare(int step) {
+    const unsigned chunk = (unsigned)(step * 8 + lch);
+    const unsigned t = fd_div(chunk, fd_cv);
+    const int cv = (int)(chunk - t * (unsigned)CV);
+    const unsigned th = fd_div(t, fd_nw);
+    const int tw = (int)(t - th * (unsigned)nw);
+    t_ok = (int)th < nh;
+    dh = dh0 + shh * (int)th;
+    dw = dw0 + sww * tw;
+    koff = (unsigned)((dh * SW + dw) * Cs + cv * VEC);
+    kbyte = (unsigned)step * IG_BKB;
+  }
+  template <int P>
+  __device__ __forceinline__ void piece(char* stage) const {
+    if constexpr (P < NAJ) {
+      const int ih = a_h[P] + dh, iw = a_w[P] + dw;
+      const int ok = t_ok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+      const unsigned off = ok ? (a_base[P] + koff) * (unsigned)sizeof(T) : OOB_OFFSET;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(stage + a_lds[P]), 16, off, 0, 0, 0);
+    } else if constexpr (P < NP) {
+      constexpr int j = P - NAJ;
+      const unsigned off = b_row[j] == OOB_OFFSET ? OOB_OFFSET : b_row[j] + kbyte;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(stage + b_lds[j]), 16, off, 0, 0, 0);
+    }
+  }
+  template <int P = 0>
+  __device__ __forceinline__ void all_pieces(char* stage) const {
+    if constexpr (P < NP) {
+      piece<P>(stage);
+      all_pieces<P + 1>(stage);
+    }
+  }
+};
+
 // one K step (2 x 64-byte halves) of a wave's TM x TN tiles, software-pipelined by hand: the B
 // fragment of tile t+2 (and the A fragments of the second half) are requested before the MFMAs of
 // tile t issue, and sched_group_barrier pins that interleave, so an MFMA group never waits for a
-// read issued right in front of it.
-template <typename T, int TM, int TN, int t>
+// read issued right in front of it.  With LOADS, loader piece t / ILV is issued behind the MFMAs of tile t.
+template <typename T, int TM, int TN, int t, bool LOADS, int ILV, typename LD>
 __device__ __forceinline__ void dma_mma_tile(f32x4 (&acc)[TM][TN], typename Mma<T>::frag (&fa)[2][TM],
                                              typename Mma<T>::frag (&fb)[2 * TN], const char* pA, const char* pB, int coff0,
-                                             int coff1) {
+                                             int coff1, const LD& ld, char* nstage) {
   using Frag = typename Mma<T>::frag;
   constexpr int NT = 2 * TN;
   if constexpr (t < NT) {
@@ -368,15 +442,20 @@ __device__ __forceinline__ void dma_mma_tile(f32x4 (&acc)[TM][TN], typename Mma<
     if constexpr (t < TM) fa[1][t] = *reinterpret_cast<const Frag*>(pA + t * 16 * IG_BKB + coff1);
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<T>::run(acc[i][j], fb[t], fa[ks][i]);
+    constexpr bool has_piece = LOADS && (t % ILV == 0) && (t / ILV < LD::NP);
+    if constexpr (has_piece) ld.template piece<t / ILV>(nstage);
     __builtin_amdgcn_sched_group_barrier(0x100, (t + 2 < NT ? 1 : 0) + (t < TM ? 1 : 0), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM * (sizeof(T) == 4 ? 4 : 1), 0);
-    dma_mma_tile<T, TM, TN, t + 1>(acc, fa, fb, pA, pB, coff0, coff1);
+    if constexpr (has_piece) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    dma_mma_tile<T, TM, TN, t + 1, LOADS, ILV, LD>(acc, fa, fb, pA, pB, coff0, coff1, ld, nstage);
   }
 }
 
-template <typename T, int TM, int TN>
-__device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* pA, const char* pB, int q, int swl) {
+template <typename T, int TM, int TN, bool LOADS, int ILV, typename LD>
+__device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* pA, const char* pB, int q, int swl, const LD& ld,
+                                             char* nstage) {
   using Frag = typename Mma<T>::frag;
+  static_assert(!LOADS || (LD::NP - 1) * ILV < 2 * TN, "every loader piece needs a tile to ride on");
   const int coff0 = ((0 * 4 + q) ^ swl) << 4, coff1 = ((1 * 4 + q) ^ swl) << 4;
   Frag fa[2][TM];
   Frag fb[2 * TN];
@@ -385,30 +464,30 @@ __device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* p
   fb[0] = *reinterpret_cast<const Frag*>(pB + coff0);
   fb[1] = *reinterpret_cast<const Frag*>(pB + 16 * IG_BKB + coff0);
   __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
-  dma_mma_tile<T, TM, TN, 0>(acc, fa, fb, pA, pB, coff0, coff1);
+  dma_mma_tile<T, TM, TN, 0, LOADS, ILV, LD>(acc, fa, fb, pA, pB, coff0, coff1, ld, nstage);
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NS>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args) {
+  static_assert(NS == 2 || NS == 3, "LDS ring depth");
   static_assert(BM % 64 == 0, "4 wave rows of BM/4 = k*16 rows, 8-row DMA instructions dealt in pairs");
-  constexpr int NAJ = BM / 64;                      // A wave-instructions per wave per step
+  using LD = DmaLoader<T, BM, BN>;
+  constexpr int NAJ = LD::NAJ;                      // A wave-instructions per wave per step
   constexpr int WMR = BM / 4;                       // rows per wave row
-  constexpr int VEC = 16 / (int)sizeof(T);
-  constexpr int BKE = IG_BKB / (int)sizeof(T);
   // waves 4 (M) x 2 (N): 64 rows x 7 or 6 column tiles.  Waves w and w+4 land on the same SIMD
   // (cyclic placement), so each SIMD carries 13 column tiles in total.
   constexpr int TM = WMR / 16, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
-  constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16; // B rows kept in LDS: both wave columns run TN tiles (the
+  constexpr int BNL = LD::BNL;                      // B rows kept in LDS: both wave columns run TN tiles (the
                                                     // second one's last tile may spill past BN and is discarded)
-  constexpr int NIB = BNL / 8;                      // B wave-instructions per step (8 rows each)
-  constexpr int NBJ = (NIB + 7) / 8;                // per wave
+  constexpr int NIB = LD::NIB;                      // B wave-instructions per step (8 rows each)
+  constexpr int NBJ = LD::NBJ;                      // per wave
   constexpr int STAGE = (BM + BNL) * IG_BKB;
+  constexpr int ILV = NS == 3 ? 2 : 1;              // tiles between loader pieces: a 2-stage ring wants them early
   static_assert(BN % 16 == 0, "tile config");
   using Frag = typename Mma<T>::frag;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  int* sTap = reinterpret_cast<int*>(smem + 2 * STAGE);
+  int* sTap = reinterpret_cast<int*>(smem + NS * STAGE);
 
   const IgClass& cl = args.cls[blockIdx.z];
   const int tid = threadIdx.x;
@@ -418,69 +497,51 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   const int M = cl.M;
   if (tile_m * BM >= M) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int ntaps = cl.ntaps;
-  const int SH = args.SH, SW = args.SW, Cs = args.Cs;
-
-  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
-  __syncthreads();
-
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
-  const __amdgpu_buffer_rsrc_t rB =
-      make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, args.w_bytes - cl.w_off_bytes);
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int par = wave & 1, wh = wave >> 1;
   const int rsub = lane >> 3;
-  const int lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
+  const int dbg = args.debug;                        // diagnostics: 4 / 5 / 6 = zero-record descriptor for A / B / both
 
-  // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(4*wh + j) + par -------------------
-  int a_h[NAJ], a_w[NAJ];
-  unsigned a_base[NAJ];
+  LD ld;
+  ld.rA = make_rsrc(args.src, (dbg == 4 || dbg == 6) ? 0u : args.src_bytes);
+  ld.rB = make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, (dbg == 5 || dbg == 6) ? 0u : args.w_bytes - cl.w_off_bytes);
+  ld.SH = args.SH; ld.SW = args.SW; ld.Cs = args.Cs; ld.CV = (int)args.fd_c.d;
+  ld.nh = cl.nh; ld.nw = cl.nw; ld.dh0 = cl.dh0; ld.dw0 = cl.dw0; ld.shh = cl.sh; ld.sww = cl.sw;
+  ld.fd_cv = args.fd_c; ld.fd_nw = cl.fd_nw;
+  ld.lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
+
+  // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(NAJ*wh + j) + par ------------------
 #pragma unroll
   for (int j = 0; j < NAJ; ++j) {
-    const int row = 8 * (2 * (NAJ * wh + j) + par) + rsub;
-    const int m = m0 + row;
+    const int I = 2 * (NAJ * wh + j) + par;
+    const int m = m0 + 8 * I + rsub;
     const bool ok = m < M;
     const unsigned mm = ok ? (unsigned)m : 0u;
     const unsigned nb = fd_div(mm, cl.fd_ghw);
     const unsigned rem = mm - nb * (unsigned)(cl.GH * cl.GW);
     const unsigned a = fd_div(rem, cl.fd_gw);
     const unsigned b = rem - a * (unsigned)cl.GW;
-    a_h[j] = ok ? (int)a * args.sigma : -(1 << 20);
-    a_w[j] = (int)b * args.sigma;
-    a_base[j] = ((nb * (unsigned)SH + a * (unsigned)args.sigma) * (unsigned)SW + b * (unsigned)args.sigma) * (unsigned)Cs;
+    ld.a_h[j] = ok ? (int)a * args.sigma : -(1 << 20);
+    ld.a_w[j] = (int)b * args.sigma;
+    ld.a_base[j] = ((nb * (unsigned)args.SH + a * (unsigned)args.sigma) * (unsigned)args.SW + b * (unsigned)args.sigma) * (unsigned)args.Cs;
+    ld.a_lds[j] = I * 1024;
   }
-  const int CV = (int)args.fd_c.d;
-  const int Kp = cl.Kp, Nn = args.N, nh = cl.nh, nw = cl.nw, dh0 = cl.dh0, dw0 = cl.dw0, shh = cl.sh, sww = cl.sw;
-  TapWalk tw;
-  tw.init(lch, args.fd_c, nw);
+  // ---- B rows: instruction I = 2*(wh + 4j) + par covers filter rows 8*I + rsub ---------------------------
+#pragma unroll
+  for (int j = 0; j < NBJ; ++j) {
+    const int I = 2 * (wh + 4 * j) + par;
+    const int n = n0 + 8 * I + rsub;
+    // pieces past the tile's BN rows (the spill rows of the second wave column, whose products are discarded, and
+    // the dummies that even out the piece count) load nothing: out-of-range source, destination inside the spill rows
+    static_assert(NIB % 8 == 0 || BNL > BN, "dummy pieces need spill rows to land in");
+    const bool useful = 8 * I < BN;                    // wave-uniform
+    ld.b_row[j] = (useful && n < args.N) ? ((unsigned)n * (unsigned)cl.Kp + (unsigned)(ld.lch * LD::VEC)) * (unsigned)sizeof(T) : OOB_OFFSET;
+    ld.b_lds[j] = BM * IG_BKB + (I < NIB ? I : NIB - 1) * 1024;
+  }
 
-  auto issue = [&](int step, int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sB = sA + BM * IG_BKB;
-    const int t_ok = tw.th < nh;
-    const int dh = dh0 + shh * tw.th, dw = dw0 + sww * tw.tw;
-    const int koff = (dh * SW + dw) * Cs + tw.cv * VEC;
-#pragma unroll
-    for (int j = 0; j < NAJ; ++j) {
-      const int I = 2 * (NAJ * wh + j) + par;
-      const int ih = a_h[j] + dh, iw = a_w[j] + dw;
-      const int ok = t_ok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
-      const unsigned off = ok ? (a_base[j] + (unsigned)koff) * (unsigned)sizeof(T) : OOB_OFFSET;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(sA + I * 1024), 16, off, 0, 0, 0);
-    }
-    tw.advance(8, CV, nw);
-    const unsigned kb = (unsigned)(step * BKE + lch * VEC);
-#pragma unroll
-    for (int j = 0; j < NBJ; ++j) {
-      const int I = 2 * (wh + 4 * j) + par;
-      if (I < NIB) {                                  // wave-uniform
-        const int n = n0 + 8 * I + rsub;
-        const unsigned off = n < Nn ? ((unsigned)n * (unsigned)Kp + kb) * (unsigned)sizeof(T) : OOB_OFFSET;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(sB + I * 1024), 16, off, 0, 0, 0);
-      }
-    }
-  };
+  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];      // (kept for layout parity with the register-staged kernel)
+  __syncthreads();
 
   const int r16 = lane & 15, q = lane >> 4;
   const int swl = (r16 >> 1) & 7;
@@ -495,17 +556,79 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nsteps = cl.nsteps;
-  issue(0, 0);
-  __syncthreads();
-  const int dbg = args.debug;
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
-    if (step + 1 < nsteps && (dbg == 0 || dbg == 3)) issue(step + 1, cur ^ 1);
-    const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
-    const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
-    if (dbg != 3)
-    dma_mma_step<T, TM, TN>(acc, pA, pB, q, swl);
+  if constexpr (NS == 2) {
+    ld.prepare(0);
+    ld.all_pieces(smem);
     __syncthreads();
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_issue = 0, s_mma = 0, s_sync = 0;
+    for (int step = 0; step < nsteps - 1; ++step) {
+      const int cur = step & 1;
+      TDG_STAMP(t0);
+      ld.prepare(step + 1);
+      TDG_STAMP(t1);
+      const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
+      const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+      char* nstage = smem + (cur ^ 1) * STAGE;
+      dma_mma_step<T, TM, TN, true, ILV, LD>(acc, pA, pB, q, swl, ld, nstage);
+      TDG_STAMP(t2);
+      __syncthreads();
+      TDG_STAMP(t3);
+      s_issue += t1 - t0; s_mma += t2 - t1; s_sync += t3 - t2;
+    }
+    {
+      const int cur = (nsteps - 1) & 1;
+      const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
+      const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+      dma_mma_step<T, TM, TN, false, ILV, LD>(acc, pA, pB, q, swl, ld, smem);
+      __syncthreads();
+    }
+#ifdef TDG_STAMPS
+    if (args.stamps && lane == 0) {
+      unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o[0] = s_issue; o[1] = s_mma; o[2] = s_sync; o[3] = (unsigned long long)(nsteps - 1);
+    }
+#endif
+  } else {
+    // 3-stage ring: the loads of step s+2 ride on the MFMAs of step s and stay in flight across the
+    // barrier that ends it; a wave waits (counted vmcnt) only for its own pieces of step s+1 before that
+    // barrier.  Raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA.
+    auto wait_barrier = [&](bool more_in_flight) {
+      if (more_in_flight) {
+        static_assert(LD::NP >= 5 && LD::NP <= 8, "add the immediate");
+        if constexpr (LD::NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        if constexpr (LD::NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if constexpr (LD::NP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+        if constexpr (LD::NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    ld.prepare(0);
+    ld.all_pieces(smem);
+    if (nsteps > 1) {
+      ld.prepare(1);
+      ld.all_pieces(smem + STAGE);
+    }
+    wait_barrier(nsteps > 1);
+    int cur = 0, step = 0;
+    for (; step < nsteps - 2; ++step) {
+      const int nxt2 = cur == 0 ? 2 : cur - 1;         // (cur + 2) % 3
+      ld.prepare(step + 2);
+      const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
+      const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+      dma_mma_step<T, TM, TN, true, ILV, LD>(acc, pA, pB, q, swl, ld, smem + nxt2 * STAGE);
+      wait_barrier(true);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
+    for (; step < nsteps; ++step) {
+      const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
+      const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+      dma_mma_step<T, TM, TN, false, ILV, LD>(acc, pA, pB, q, swl, ld, smem);
+      wait_barrier(false);
+      cur = cur == 2 ? 0 : cur + 1;
+    }
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
@@ -522,7 +645,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     if (!accum && (N & 7) == 0) {
       constexpr int PE = BN * 2 + 16;                          // row pitch: +16 B keeps the 8-byte writes spread over banks
       constexpr int CPR = BN * 2 / 16;                         // 16-byte chunks per row
-      static_assert(BM * PE + BM * 8 <= 2 * STAGE, "epilogue staging must fit the ring");
+      static_assert(BM * PE + BM * 8 <= NS * STAGE, "epilogue staging must fit the ring");
       char* sE = smem;
       long long* sPix = reinterpret_cast<long long*>(smem + BM * PE);
       if (tid < BM) {
@@ -1146,21 +1269,22 @@ int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStre
   return TDG_OK;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NS>
 int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
   a.ntiles_n = tdg_ceil_div(a.N, BN);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
-  const size_t lds = 2 * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
+  const size_t lds = NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
-  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS>), grid, block, lds, s, a);
   tdg_note_kernel(BM == 256 ? (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,256,208>" : "igemm_fwd_dma_kernel<f32,256,208>")
-                            : (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,192,208>" : "igemm_fwd_dma_kernel<f32,192,208>"));
+                  : BM == 192 ? (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,192,208>" : "igemm_fwd_dma_kernel<f32,192,208>")
+                              : (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,128,208>" : "igemm_fwd_dma_kernel<f32,128,208>"));
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
 }
@@ -1172,18 +1296,35 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   const char* dma_env = getenv("TDG_DMA");          // diagnostics: 0 = never, 3 / 4 = force the 192 / 256-row tile
   const int dma_mode = dma_env ? atoi(dma_env) : 1;
   a.debug = dbg;
+#ifdef TDG_STAMPS
+  a.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
   int mmax = 0;
   for (int c = 0; c < a.nclasses; ++c) mmax = a.cls[c].M > mmax ? a.cls[c].M : mmax;
   // large problems: 256-row tiles fed by LDS-DMA (needs >= ~1 workgroup per CU to pay off)
   // 208-column problems with a vector gather always take the LDS-DMA kernel (measured faster than the
   // register-staged one even when the grid does not fill the chip)
   if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
-    // one 8-wave workgroup per CU: pick the row tile whose workgroup count wastes less of the last round
+    // one 8-wave workgroup per CU.  Row tiles: 256 (2-stage LDS ring), 192 and 128 (3-stage ring, loads two
+    // steps ahead).  Cost model: rounds of 256 workgroups x rows per tile / measured relative efficiency.
     const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
-    const long long t256 = per * tdg_ceil_div(mmax, 256), t192 = per * tdg_ceil_div(mmax, 192);
-    const double e256 = (double)t256 / (tdg_ceil_div(t256, 256) * 256.0), e192 = (double)t192 / (tdg_ceil_div(t192, 256) * 256.0);
-    if (dma_mode == 3 || (dma_mode != 4 && e192 > e256 + 0.08)) return launch_fwd_dma<T, 192, 208>(a, mmax, s);
-    return launch_fwd_dma<T, 256, 208>(a, mmax, s);
+    static const int force = getenv("TDG_DMA_BM") ? atoi(getenv("TDG_DMA_BM")) : 0;   // diagnostics
+    const int bms[3] = {256, 192, 128};
+    const double eff[3] = {0.92, 1.0, 0.85};
+    int best = 0;
+    double best_cost = 1e30;
+    for (int i = 0; i < 3; ++i) {
+      const long long tiles = per * tdg_ceil_div(mmax, bms[i]);
+      const double cost = (double)tdg_ceil_div(tiles, 256) * bms[i] / eff[i];
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = i; }
+    }
+    int bm = force ? force : bms[best];
+    if (dma_mode == 3) bm = 192;
+    if (dma_mode == 4) bm = 256;
+    static const int ring192 = getenv("TDG_RING") ? atoi(getenv("TDG_RING")) : 3;     // diagnostics: 2 = 2-stage ring on the 192-row tile
+    if (bm == 128) return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
+    if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
+    return launch_fwd_dma<T, 256, 208, 2>(a, mmax, s);
   }
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
@@ -1447,6 +1588,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) c.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
   c.nh = d->kh; c.nw = d->kw; c.dh0 = -d->pad_t; c.dw0 = -d->pad_l; c.sh = c.sw = 1;
+  c.fd_nw = make_fastdiv(c.nw);
   const int bn = pick_bn(d->k);
   return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
                               : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
@@ -1501,6 +1643,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     c.fd_gw = make_fastdiv(c.GW);
     for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(plan[i].dh[t], plan[i].dw[t]);
     c.nh = plan[i].nh; c.nw = plan[i].nw; c.dh0 = plan[i].dh[0]; c.dw0 = plan[i].dw[0]; c.sh = c.sw = -1;
+    c.fd_nw = make_fastdiv(c.nw);
     off += (unsigned)((size_t)d->c * Kp * es);
   }
   const int bn = pick_bn(d->c);

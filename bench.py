@@ -117,7 +117,7 @@ def main():
     # are repeated eagerly, directly after the timed region, with every conv GEMM launch bracketed by events
     # on the launch stream (rank 0 only; the other ranks run the same steps so collectives stay matched).
     timer = None
-    if not args.no_kernel_timer:
+    if not args.no_kernel_timer and args.timer_steps > 0:
         rep.use_graphs = False
         rep.train_func()
         if sess.rank == 0:
