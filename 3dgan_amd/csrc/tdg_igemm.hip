@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "tdg_igemm.h"
+#include <type_traits>
 
 #define OOB_OFFSET 0xFFFFFF00u
 
@@ -55,6 +56,18 @@ struct Mma<float> {
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+
+// Raw buffer descriptor as four SGPR dwords, and an LDS-DMA load (`buffer_load_dwordx4 ... offen lds`) issued
+// from inline asm.  hipcc tracks the builtin form as a pending LDS write and puts `s_waitcnt vmcnt(0)` in front
+// of the next `ds_read_b64_tr_b16` (the transposing reads of the filter-gradient kernel), which serialises load and
+// multiply; the asm form is invisible to that pass, so the kernel drains it by hand (vmcnt before its barrier).
+__device__ __forceinline__ i32x4 make_rsrc_words(const void* p, unsigned bytes) {
+  const unsigned long long a = (unsigned long long)p;
+  return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void lds_dma_b128(const i32x4& rsrc, unsigned voff, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rsrc), "s"(lds_byte) : "memory");
 }
 
 template <typename T>
@@ -1011,9 +1024,52 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const WgArgs args) 
 #define WD_ROWB 512
 __device__ __forceinline__ int wd_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <int TK, int TN, int t, typename FragFn>
+// Loader of igemm_wgrad_dma_kernel as 8 single wave-instructions ("pieces") per wave and step: piece 2j is the
+// j-th 2-row instruction of the gathered operand, piece 2j+1 the same rows of the dense one.  The K loop issues
+// one piece behind each of the first 8 MFMA groups of a step (see DmaLoader).
+struct WdLoader {
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  i32x4 rA, rG;
+  unsigned lds0;                    // LDS byte address of the ring
+  FastDiv fd_ghw, fd_gw;
+  int GHW, GW, SH, SW, Cs, sigma, Gs, m_end;
+  int a_dh, a_dw, a_koff, a_kok, g_n, g_nok, hrow;
+  int Ibase;                        // b0 | b2 << 2 | b4 << 4
+  template <int P>
+  __device__ __forceinline__ void piece(int mstep, int stage_off) const {
+    constexpr int j = P >> 1;
+    constexpr int SLABB = WD_MR * WD_ROWB;
+    const int I = Ibase | ((j & 1) << 1) | ((j >> 1) << 3);
+    const int m = mstep + 2 * I + hrow;
+    const int okm = m < m_end;
+    if constexpr ((P & 1) == 0) {
+      const unsigned mm = okm ? (unsigned)m : 0u;
+      const unsigned nb = fd_div(mm, fd_ghw);
+      const unsigned rem = mm - nb * (unsigned)GHW;
+      const unsigned a = fd_div(rem, fd_gw);
+      const unsigned b = rem - a * (unsigned)GW;
+      const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
+      const int ok = okm & a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+      const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
+      const unsigned offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
+      lds_dma_b128(rA, offa, lds0 + (unsigned)(stage_off + I * 1024));
+    } else {
+      const unsigned offg = (okm & g_nok) ? ((unsigned)m * (unsigned)Gs + (unsigned)g_n) * 2u : OOB_OFFSET;
+      lds_dma_b128(rG, offg, lds0 + (unsigned)(stage_off + SLABB + I * 1024));
+    }
+  }
+  template <int P = 0>
+  __device__ __forceinline__ void all_pieces(int mstep, int stage_off) const {
+    if constexpr (P < 8) {
+      piece<P>(mstep, stage_off);
+      all_pieces<P + 1>(mstep, stage_off);
+    }
+  }
+};
+
+template <int TK, int TN, int t, bool LOADS, typename FragFn>
 __device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2][TK], bf16x8 (&fg)[2 * TN], const char* sA,
-                                            const char* sG, int wk, int wn, FragFn& frag) {
+                                            const char* sG, int wk, int wn, FragFn& frag, const WdLoader& ld, int nmstep, int nstage) {
   constexpr int NT = 2 * TN;
   if constexpr (t < NT) {
     constexpr int ks = t / TN, j = t - ks * TN;
@@ -1024,9 +1080,12 @@ __device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2
     if constexpr (t < TK) fa[1][t] = frag(sA, 1, wk * 64 + t * 16);
 #pragma unroll
     for (int i = 0; i < TK; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[t], fa[ks][i], acc[i][j], 0, 0, 0);
+    constexpr bool has_piece = LOADS && t < 8;
+    if constexpr (has_piece) ld.template piece<t>(nmstep, nstage);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((t + 1 < NT ? 1 : 0) + (t < TK ? 1 : 0)), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
-    wd_mma_tile<TK, TN, t + 1>(acc, fa, fg, sA, sG, wk, wn, frag);
+    if constexpr (has_piece) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    wd_mma_tile<TK, TN, t + 1, LOADS>(acc, fa, fg, sA, sG, wk, wn, frag, ld, nmstep, nstage);
   }
 }
 
@@ -1056,8 +1115,8 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
   if (tid < IG_MAX_TAPS) sTap[tid] = args.tap[tid];
   __syncthreads();
 
-  const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
-  const __amdgpu_buffer_rsrc_t rG = make_rsrc(args.g, args.g_bytes);
+  const i32x4 rA = make_rsrc_words(args.src, args.src_bytes);
+  const i32x4 rG = make_rsrc_words(args.g, args.g_bytes);
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int hrow = lane >> 5;                                   // row inside a 2-row DMA instruction
@@ -1081,28 +1140,13 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
   const int g_n = n0 + lch * VEC;
   const bool g_nok = (lch * VEC < TN * 32) && (g_n < args.N);
 
-  auto issue = [&](int mstep, int stage) {
-    char* sA = smem + stage * STAGE;
-    char* sG = sA + SLAB;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int I = b0 | ((j & 1) << 1) | (b2 << 2) | ((j >> 1) << 3) | (b4 << 4);
-      const int m = mstep + 2 * I + hrow;
-      const int okm = m < m_end;
-      const unsigned mm = okm ? (unsigned)m : 0u;
-      const unsigned nb = fd_div(mm, args.fd_ghw);
-      const unsigned rem = mm - nb * (unsigned)GHW;
-      const unsigned a = fd_div(rem, args.fd_gw);
-      const unsigned b = rem - a * (unsigned)GW;
-      const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
-      const int ok = okm & (int)a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
-      const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
-      const unsigned offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(sA + I * 1024), 16, offa, 0, 0, 0);
-      const unsigned offg = (okm & (int)g_nok) ? ((unsigned)m * (unsigned)Gs + (unsigned)g_n) * 2u : OOB_OFFSET;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rG, (lds_ptr_t)(sG + I * 1024), 16, offg, 0, 0, 0);
-    }
-  };
+  WdLoader ld;
+  ld.rA = rA; ld.rG = rG;
+  ld.lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  ld.fd_ghw = args.fd_ghw; ld.fd_gw = args.fd_gw;
+  ld.GHW = GHW; ld.GW = GW; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.Gs = Gs; ld.m_end = m_end;
+  ld.a_dh = a_dh; ld.a_dw = a_dw; ld.a_koff = a_koff; ld.a_kok = (int)a_kok; ld.g_n = g_n; ld.g_nok = (int)g_nok; ld.hrow = hrow;
+  ld.Ibase = b0 | (b2 << 2) | (b4 << 4);
 
   const int r16 = lane & 15, q = lane >> 4;
   const int wk = wave & 3, wn = wave >> 2;
@@ -1127,25 +1171,32 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  issue(m_begin, 0);
-  __syncthreads();
-  int stage = 0;
-  for (int mstep = m_begin; mstep < m_end; mstep += WD_MR) {
-    if (mstep + WD_MR < m_end) issue(mstep + WD_MR, stage ^ 1);
+  auto step_mma = [&](auto loads, int stage, int nmstep) {
+    constexpr bool LOADS = decltype(loads)::value;
     const char* sA = smem + stage * STAGE;
     const char* sG = sA + SLAB;
-    {
-      // software-pipelined: the fragment of column tile t+1 is requested before the MFMAs of tile t
-      bf16x8 fa[2][TK];
-      bf16x8 fg[2 * TN];
+    // software-pipelined: the fragment of column tile t+1 is requested before the MFMAs of tile t
+    bf16x8 fa[2][TK];
+    bf16x8 fg[2 * TN];
 #pragma unroll
-      for (int i = 0; i < TK; ++i) fa[0][i] = frag(sA, 0, wk * 64 + i * 16);
-      fg[0] = frag(sG, 0, (wn * TN) * 16);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 2, 0);
-      wd_mma_tile<TK, TN, 0>(acc, fa, fg, sA, sG, wk, wn, frag);
-    }
+    for (int i = 0; i < TK; ++i) fa[0][i] = frag(sA, 0, wk * 64 + i * 16);
+    fg[0] = frag(sG, 0, (wn * TN) * 16);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 2, 0);
+    wd_mma_tile<TK, TN, 0, LOADS>(acc, fa, fg, sA, sG, wk, wn, frag, ld, nmstep, (stage ^ 1) * STAGE);
+  };
+  ld.all_pieces(m_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm-issued LDS-DMA is not counted by the compiler
+  __syncthreads();
+  int stage = 0, mstep = m_begin;
+  for (; mstep + WD_MR < m_end; mstep += WD_MR) {
+    step_mma(std::true_type{}, stage, mstep + WD_MR);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     stage ^= 1;
+  }
+  if (mstep < m_end) {
+    step_mma(std::false_type{}, stage, 0);
+    __syncthreads();
   }
 
   // ---- epilogue: lane owns filter row kk (r16) x 4 consecutive n ----------------------------------
