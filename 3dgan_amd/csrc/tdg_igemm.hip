@@ -1289,6 +1289,148 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
 }
 
 // ============================================================================================
+// Stride-2 backward-data with a thin big side (4*C <= 16 columns: the discriminator's first layer and the
+// generator's last): all four output-parity classes in ONE pass.  A workgroup stages the small-side rows
+// it needs (TA anchor rows + halo, every channel) in LDS once and multiplies them with the merged filter
+// W[(class, c)][tap of the union tap grid][k] (zeros where a class has no such tap), 16 columns wide.
+// The class-per-launch-z form re-read the small side once per class and tap through L2 (0.78 ms for
+// 1536 x 16x16x200 -> 32x32x3); here it is read once from HBM.   bf16 only.
+// ============================================================================================
+struct FusedBwdArgs {
+  const bf16_t* y;       // small side [n][SH][SW][Cs]
+  const bf16_t* w;       // merged filter [16][wpitch]
+  bf16_t* x;             // big side [n][OH][OW][Cso]
+  const float* bias;
+  const bf16_t* mask_src;
+  int SH, SW, Cs, ke;    // ke: channels staged per pixel (multiple of 8)
+  int OH, OW, Cso, C;    // C: logical big-side channels per class
+  int GH, GW;            // anchor grid (ceil(OH/2), ceil(OW/2))
+  int nhm, nwm, dh_min, dw_min, ntap;
+  int KP, PP, wpitch;    // K per tap padded to 32; LDS pixel pitch; filter column pitch (elements)
+  int TA, ntr;           // anchor rows per workgroup, row tiles per image
+  int y_off;             // LDS byte offset of the halo tile
+  FastDiv fd_vpp, fd_hc;
+  int act, mask_mode, accumulate;
+  float leak;
+};
+
+__global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
+  constexpr int NTHR = 512, NWAVE = NTHR / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
+  bf16_t* sY = reinterpret_cast<bf16_t*>(smem + a.y_off);     // past the zero-filled tail of the filter's last wave instruction
+  const int tid = threadIdx.x;
+  const int img = blockIdx.x / a.ntr, rt = blockIdx.x - img * a.ntr;
+  const int a0 = rt * a.TA;
+  const int HR = a.TA + a.nhm - 1, HC = a.GW + a.nwm - 1;     // halo tile (pixels)
+
+  // ---- stage the merged filter (straight copy) and the halo tile by LDS-DMA: every 16-byte chunk of both images
+  // is one lane of a wave instruction (destination lane-linear), halo pixels outside the image, the pitch padding
+  // and the slack behind the last pixel come from out-of-range sources (zero fill), so all loads are in flight at
+  // once and one wait ends the staging (with one workgroup per CU it was latency-bound as load/store batches)
+  const int wave = tid >> 6, lane = tid & 63;
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w, (unsigned)(16 * a.wpitch * 2));
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.y + (size_t)img * a.SH * a.SW * a.Cs, (unsigned)(a.SH * a.SW * a.Cs * 2));
+    const int nvW = 16 * a.wpitch / 8;
+    for (int g0 = wave * 64; g0 < nvW; g0 += NWAVE * 64) {
+      const int g = g0 + lane;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + g0 * 16), 16, g < nvW ? (unsigned)g * 16u : OOB_OFFSET, 0, 0, 0);
+    }
+    const int vpp = a.PP / 8, vreal = a.ke / 8, npx = HR * HC;
+    const int nvY = npx * vpp + a.KP / 8;
+    char* sYb = reinterpret_cast<char*>(sY);
+    for (int g0 = wave * 64; g0 < nvY; g0 += NWAVE * 64) {
+      const int g = g0 + lane;
+      const int pix = (int)fd_div((unsigned)g, a.fd_vpp), v = g - pix * vpp;
+      const int hr = (int)fd_div((unsigned)pix, a.fd_hc), hc = pix - hr * HC;
+      const int r = a0 + hr + a.dh_min, c = hc + a.dw_min;
+      const bool ok = pix < npx && v < vreal && (unsigned)r < (unsigned)a.SH && (unsigned)c < (unsigned)a.SW;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, (lds_ptr_t)(sYb + g0 * 16), 16, ok ? (unsigned)(((r * a.SW + c) * a.Cs + v * 8) * 2) : OOB_OFFSET, 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  const int r16 = lane & 15, q = lane >> 4;
+  const int npix = a.TA * a.GW, ntile = (npix + 15) / 16;
+  const int kcn = a.KP / 32;
+  const bf16_t* wrow = sW + r16 * a.wpitch + q * 8;
+  for (int t0 = wave; t0 < ntile; t0 += 2 * NWAVE) {
+    // two 16-pixel tiles share every filter fragment
+    const int t1 = t0 + NWAVE;
+    const bool has1 = t1 < ntile;
+    int p0 = t0 * 16 + r16, p1 = t1 * 16 + r16;
+    const bool ok0 = p0 < npix, ok1 = has1 && p1 < npix;
+    p0 = ok0 ? p0 : 0;
+    p1 = ok1 ? p1 : 0;
+    const int al0 = p0 / a.GW, b0 = p0 - al0 * a.GW;
+    const int al1 = p1 / a.GW, b1 = p1 - al1 * a.GW;
+    const bf16_t* base0 = sY + (size_t)(al0 * HC + b0) * a.PP + q * 8;
+    const bf16_t* base1 = sY + (size_t)(al1 * HC + b1) * a.PP + q * 8;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    for (int th = 0; th < a.nhm; ++th)
+      for (int tw = 0; tw < a.nwm; ++tw) {
+        const int toff = (th * HC + tw) * a.PP;
+        const bf16_t* wt = wrow + (th * a.nwm + tw) * a.KP;
+#pragma unroll 4
+        for (int kc = 0; kc < kcn; ++kc) {
+          const bf16x8 fw = *reinterpret_cast<const bf16x8*>(wt + kc * 32);
+          const bf16x8 f0 = *reinterpret_cast<const bf16x8*>(base0 + toff + kc * 32);
+          const bf16x8 f1 = *reinterpret_cast<const bf16x8*>(base1 + toff + kc * 32);
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, f0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, f1, acc1, 0, 0, 0);
+        }
+      }
+    // ---- epilogue: lane holds columns 4q..4q+3 = (class, c) of its pixel ------------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const bool ok = h ? ok1 : ok0;
+      if (!ok) continue;
+      const f32x4 acc = h ? acc1 : acc0;
+      const int ar = a0 + (h ? al1 : al0), bc = h ? b1 : b0;
+      if (ar >= a.GH) continue;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int col = q * 4 + e;
+        const int cls = col / a.C, c = col - cls * a.C;
+        if (cls >= 4) continue;
+        const int oy = 2 * ar + (cls >> 1), ox = 2 * bc + (cls & 1);
+        if (oy >= a.OH || ox >= a.OW) continue;
+        const size_t o = (((size_t)img * a.OH + oy) * a.OW + ox) * a.Cso + c;
+        float v = acc[e] + (a.bias ? a.bias[c] : 0.f);
+        v = apply_act(v, a.act, a.leak);
+        if (a.accumulate) v += (float)a.x[o];
+        if (a.mask_mode != TDG_MASK_NONE) v *= mask_factor((float)a.mask_src[o], a.mask_mode, a.leak);
+        a.x[o] = (bf16_t)v;
+      }
+    }
+  }
+}
+
+// merged filter of bwd_fused_kernel from the f32 master [kh][kw][c][k]
+struct FusedPackArgs {
+  const float* w;
+  bf16_t* out;
+  int C, K, KH, KW, pad_t, pad_l;
+  int nhm, nwm, dh_min, dw_min, KP, wpitch;
+};
+__global__ void __launch_bounds__(256) pack_fused_kernel(const FusedPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 16 * a.wpitch) return;
+  const int col = i / a.wpitch, r = i - col * a.wpitch;
+  float v = 0.f;
+  const int cls = col / a.C, c = col - cls * a.C;
+  const int tap = r / a.KP, k = r - tap * a.KP;
+  if (cls < 4 && tap < a.nhm * a.nwm && k < a.K) {
+    const int th = tap / a.nwm, tw = tap - th * a.nwm;
+    const int kh = (cls >> 1) + a.pad_t - 2 * (a.dh_min + th), kw = (cls & 1) + a.pad_l - 2 * (a.dw_min + tw);
+    if (kh >= 0 && kh < a.KH && kw >= 0 && kw < a.KW) v = a.w[(((size_t)kh * a.KW + kw) * a.C + c) * a.K + k];
+  }
+  a.out[i] = (bf16_t)v;
+}
+
+// ============================================================================================
 // host side: planning + launch
 // ============================================================================================
 namespace {
@@ -1504,6 +1646,54 @@ int plan_bwd_classes(const TdgConvDesc* d, BwdClassPlan* cls) {
   return nc;
 }
 
+// ---- fused-class backward-data (bwd_fused_kernel): when it applies and its geometry ---------------------------
+struct FusedPlan {
+  int nhm, nwm, dh_min, dw_min, ntap, ke, KP, PP, wpitch, TA, ntr, GH, GW, y_off;
+  size_t w_bytes, lds;
+};
+
+bool plan_bwd_fused(const TdgConvDesc* d, FusedPlan* f) {
+  static const int enabled = getenv("TDG_FUSE") ? atoi(getenv("TDG_FUSE")) : 1;   // diagnostics: 0 = one launch-z per class
+  if (!enabled || d->dtype != TDG_BF16 || d->stride != 2 || 4 * d->c > 16) return false;
+  if (d->kh < 2 || d->kw < 2) return false;                  // every class needs a tap
+  const int ke = eff_channels(d->k, d->ks, 8);
+  if (!ke) return false;
+  BwdClassPlan cls[IG_MAX_CLASSES];
+  const int nc = plan_bwd_classes(d, cls);
+  int dh_lo = 1 << 20, dh_hi = -(1 << 20), dw_lo = 1 << 20, dw_hi = -(1 << 20);
+  for (int i = 0; i < nc; ++i)
+    for (int t = 0; t < cls[i].ntaps; ++t) {
+      dh_lo = cls[i].dh[t] < dh_lo ? cls[i].dh[t] : dh_lo;
+      dh_hi = cls[i].dh[t] > dh_hi ? cls[i].dh[t] : dh_hi;
+      dw_lo = cls[i].dw[t] < dw_lo ? cls[i].dw[t] : dw_lo;
+      dw_hi = cls[i].dw[t] > dw_hi ? cls[i].dw[t] : dw_hi;
+    }
+  f->nhm = dh_hi - dh_lo + 1;
+  f->nwm = dw_hi - dw_lo + 1;
+  f->dh_min = dh_lo;
+  f->dw_min = dw_lo;
+  f->ntap = f->nhm * f->nwm;
+  f->ke = ke;
+  f->KP = (int)tdg_round_up(ke, 32);
+  f->PP = ((ke / 8) & 1) ? ke : ke + 8;                       // odd number of 16-byte chunks per pixel: conflict-free fragment reads
+  f->wpitch = f->ntap * f->KP + 8;                            // (ntap * KP / 8 is even)
+  f->GH = (d->h + 1) / 2;
+  f->GW = (d->w + 1) / 2;
+  f->w_bytes = (size_t)16 * f->wpitch * 2;
+  const size_t budget = 150 * 1024;
+  const size_t row_bytes = (size_t)(f->GW + f->nwm - 1) * f->PP * 2;
+  f->y_off = (int)tdg_round_up((long long)f->w_bytes, 1024);
+  const size_t fixed = (size_t)f->y_off + (size_t)f->KP * 2 + 1024;   // + slack + the tail of the halo's last wave instruction
+  if (fixed + (size_t)f->nhm * row_bytes > budget) return false;
+  int ta = (int)((budget - fixed) / row_bytes) - (f->nhm - 1);
+  if (ta > f->GH) ta = f->GH;
+  if (ta < 1) return false;
+  f->ntr = tdg_ceil_div(f->GH, ta);
+  f->TA = tdg_ceil_div(f->GH, f->ntr);                        // balanced row tiles
+  f->lds = fixed + (size_t)(f->TA + f->nhm - 1) * row_bytes;
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1522,6 +1712,8 @@ size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
   int ke = eff_channels(d->k, d->ks, vec);
   if (!ke) ke = d->k;
+  FusedPlan fp;
+  if (plan_bwd_fused(d, &fp)) return fp.w_bytes;
   BwdClassPlan cls[IG_MAX_CLASSES];
   const int nc = plan_bwd_classes(d, cls);
   size_t total = 0;
@@ -1560,6 +1752,17 @@ int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void
   int rc = validate_desc(d, "tdg_pack_filter_bwd");
   if (rc) return rc;
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
+  FusedPlan fp;
+  if (plan_bwd_fused(d, &fp)) {
+    FusedPackArgs a;
+    a.w = w;
+    a.out = static_cast<bf16_t*>(packed);
+    a.C = d->c; a.K = d->k; a.KH = d->kh; a.KW = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+    a.nhm = fp.nhm; a.nwm = fp.nwm; a.dh_min = fp.dh_min; a.dw_min = fp.dw_min; a.KP = fp.KP; a.wpitch = fp.wpitch;
+    hipLaunchKernelGGL(pack_fused_kernel, dim3(tdg_ceil_div(16 * fp.wpitch, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    TDG_HIP_LAUNCH_CHECK("pack_filter_bwd(fused)");
+    return TDG_OK;
+  }
   int ke = eff_channels(d->k, d->ks, vec);
   if (!ke) ke = d->k;
   BwdClassPlan cls[IG_MAX_CLASSES];
@@ -1657,6 +1860,36 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
   const bool veca = ke != 0;
   const int C = veca ? ke : d->k;
   TDG_CHECK_ARG(!veca || ((uintptr_t)y & 15) == 0, "tdg_conv2d_bwd_data: y must be 16-byte aligned (channel stride allows the vector gather)");
+  FusedPlan fp;
+  if (plan_bwd_fused(d, &fp)) {
+    FusedBwdArgs f;
+    memset(&f, 0, sizeof(f));
+    f.y = static_cast<const bf16_t*>(y);
+    f.w = static_cast<const bf16_t*>(wp);
+    f.x = static_cast<bf16_t*>(x);
+    f.bias = epi ? epi->bias : nullptr;
+    f.act = epi ? epi->act : TDG_ACT_NONE;
+    f.leak = epi ? epi->leak : 0.f;
+    f.mask_mode = epi ? epi->mask_mode : TDG_MASK_NONE;
+    f.mask_src = f.mask_mode != TDG_MASK_NONE ? static_cast<const bf16_t*>(epi->mask_src) : nullptr;
+    f.accumulate = epi ? epi->accumulate : 0;
+    f.SH = d->oh; f.SW = d->ow; f.Cs = d->ks; f.ke = fp.ke;
+    f.OH = d->h; f.OW = d->w; f.Cso = d->cs; f.C = d->c;
+    f.GH = fp.GH; f.GW = fp.GW;
+    f.nhm = fp.nhm; f.nwm = fp.nwm; f.dh_min = fp.dh_min; f.dw_min = fp.dw_min; f.ntap = fp.ntap;
+    f.KP = fp.KP; f.PP = fp.PP; f.wpitch = fp.wpitch; f.TA = fp.TA; f.ntr = fp.ntr; f.y_off = fp.y_off;
+    f.fd_vpp = make_fastdiv(fp.PP / 8);
+    f.fd_hc = make_fastdiv(fp.GW + fp.nwm - 1);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr), dim3(512), fp.lds, (hipStream_t)stream, f);
+    tdg_note_kernel("bwd_fused_kernel<bf16>");
+    TDG_HIP_LAUNCH_CHECK("bwd_fused");
+    return TDG_OK;
+  }
   IgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = y;

@@ -36,6 +36,8 @@ CONV_CASES = [
     (5, 1, 1, 24, 136, 1, 1),      # dense as 1x1 conv on 1x1 images (fc1)
     (2, 7, 9, 12, 20, 5, 2),       # odd spatial sizes
     (2, 16, 16, 3, 100, 5, 2),     # dc4 geometry: big side c=3 (scalar), small side 100 -> stride 104
+    (3, 7, 9, 3, 24, 5, 2),        # thin big side, odd sizes: fused-class backward-data with ragged parity classes
+    (2, 32, 32, 1, 40, 5, 2),      # one channel (mnist): fused-class backward-data, row-tiled
 ]
 
 
