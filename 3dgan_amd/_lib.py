@@ -28,6 +28,11 @@ class Epilogue(C.Structure):
                 ('mask_mode', C.c_int32), ('mask_src', C.c_void_p), ('accumulate', C.c_int32)]
 
 
+class PackJob(C.Structure):
+    """TdgPackJob (include/tdg.h)."""
+    _fields_ = [('desc', ConvDesc), ('w', C.c_void_p), ('packed_fwd', C.c_void_p), ('packed_bwd', C.c_void_p)]
+
+
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _PD, _PE = C.POINTER(ConvDesc), C.POINTER(Epilogue)
 
@@ -40,6 +45,7 @@ SIGNATURES = {
     'tdg_packed_filter_bwd_bytes': (_sz, [_PD]),
     'tdg_pack_filter_fwd': (_i, [_PD, _vp, _vp, _vp]),
     'tdg_pack_filter_bwd': (_i, [_PD, _vp, _vp, _vp]),
+    'tdg_pack_filters': (_i, [C.POINTER(PackJob), _i, _vp]),
     'tdg_conv2d_fwd': (_i, [_PD, _i, _vp, _vp, _vp, _PE, _vp]),
     'tdg_conv2d_bwd_data': (_i, [_PD, _i, _vp, _vp, _vp, _PE, _vp]),
     'tdg_conv2d_bwd_filter_workspace_bytes': (_sz, [_PD, _i]),

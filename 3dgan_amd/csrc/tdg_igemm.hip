@@ -395,22 +395,25 @@ struct DmaLoader {
   unsigned a_base[NAJ];
   unsigned b_row[NBJ];          // byte offset of this lane's chunk at step 0; OOB_OFFSET: row outside N or dummy piece
   int a_lds[NAJ], b_lds[NBJ];   // wave-uniform byte offsets inside a stage
-  int SH, SW, Cs, CV, nh, nw, dh0, dw0, shh, sww, lch;
-  FastDiv fd_cv, fd_nw;
+  int SH, SW, Cs, CV, ntaps, lch;
+  int tapreg;                   // the class's tap table, entry (lane & 31) in each lane
+  FastDiv fd_cv;
   // state of the step being loaded
   int dh, dw, t_ok;
   unsigned koff, kbyte;
 
   // K chunk (step, lch) -> tap (th, tw) and 16-byte vector cv inside the tap's channels
+  // (the tap's source offset comes from the class's tap table: the table's ORDER is the K order of the packed
+  //  filter, which the host is free to choose -- see fwd_tap_order)
   __device__ __forceinline__ void prepare(int step) {
     const unsigned chunk = (unsigned)(step * 8 + lch);
     const unsigned t = fd_div(chunk, fd_cv);
     const int cv = (int)(chunk - t * (unsigned)CV);
-    const unsigned th = fd_div(t, fd_nw);
-    const int tw = (int)(t - th * (unsigned)nw);
-    t_ok = (int)th < nh;
-    dh = dh0 + shh * (int)th;
-    dw = dw0 + sww * tw;
+    t_ok = (int)t < ntaps;
+    const int pk = __builtin_amdgcn_ds_bpermute((int)(t_ok ? t : 0u) << 2, tapreg);   // lane i holds tap i: a lane crossbar
+    dh = tap_dh(pk);                                                                  // read, not an LDS access the
+                                                                                      // compiler would fence the DMA for
+    dw = tap_dw(pk);
     koff = (unsigned)((dh * SW + dw) * Cs + cv * VEC);
     kbyte = (unsigned)step * IG_BKB;
   }
@@ -520,8 +523,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   ld.rA = make_rsrc(args.src, (dbg == 4 || dbg == 6) ? 0u : args.src_bytes);
   ld.rB = make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, (dbg == 5 || dbg == 6) ? 0u : args.w_bytes - cl.w_off_bytes);
   ld.SH = args.SH; ld.SW = args.SW; ld.Cs = args.Cs; ld.CV = (int)args.fd_c.d;
-  ld.nh = cl.nh; ld.nw = cl.nw; ld.dh0 = cl.dh0; ld.dw0 = cl.dw0; ld.shh = cl.sh; ld.sww = cl.sw;
-  ld.fd_cv = args.fd_c; ld.fd_nw = cl.fd_nw;
+  ld.ntaps = cl.ntaps; ld.tapreg = cl.tap[lane & (IG_MAX_TAPS - 1)];
+  ld.fd_cv = args.fd_c;
   ld.lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
 
   // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(NAJ*wh + j) + par ------------------
@@ -553,7 +556,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     ld.b_lds[j] = BM * IG_BKB + (I < NIB ? I : NIB - 1) * 1024;
   }
 
-  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];      // (kept for layout parity with the register-staged kernel)
+  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
   __syncthreads();
 
   const int r16 = lane & 15, q = lane >> 4;
@@ -618,11 +621,13 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
-    ld.prepare(0);
-    ld.all_pieces(smem);
-    if (nsteps > 1) {
-      ld.prepare(1);
-      ld.all_pieces(smem + STAGE);
+    {
+      // both steps' tap lookups before the first DMA: a DS instruction behind a pending LDS-DMA gets a vmcnt(0)
+      LD l1 = ld;
+      ld.prepare(0);
+      l1.prepare(1);                                 // (past the last step: every piece out of range)
+      ld.all_pieces(smem);
+      if (nsteps > 1) l1.all_pieces(smem + STAGE);
     }
     wait_barrier(nsteps > 1);
     int cur = 0, step = 0;
@@ -1255,14 +1260,13 @@ struct PackArgs {
   void* out;
   int rows, ntaps, C, Ceff, Kp;
   int stride_tap, stride_row, stride_ch;
-  int tap_ids[IG_MAX_TAPS];
+  unsigned char tap_ids[IG_MAX_TAPS];
 };
 
+// one (row tile of 32, k tile of 32) with an LDS transpose so both sides coalesce
 template <typename T>
-__global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
-  // one block per (row tile of 32, k tile of 32) with an LDS transpose so both sides coalesce
-  __shared__ float tile[32][33];
-  const int k0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+__device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by, float (*tile)[33]) {
+  const int k0 = bx * 32, r0 = by * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const bool row_fast = a.stride_row == 1;                  // which source index is contiguous
 #pragma unroll
@@ -1286,6 +1290,33 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
     const int r = r0 + rl, k = k0 + tx;
     if (r < a.rows && k < a.Kp) out[(size_t)r * a.Kp + k] = from_f32<T>(tile[tx][rl]);
   }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
+  __shared__ float tile[32][33];
+  pack_tile<T>(a, blockIdx.x, blockIdx.y, tile);
+}
+
+// several packing jobs in one launch: block b belongs to the job j with start[j] <= b < start[j+1]
+#define PACK_MULTI_MAX 36
+struct PackMultiArgs {
+  int njobs;
+  int start[PACK_MULTI_MAX + 1];
+  PackArgs job[PACK_MULTI_MAX];
+};
+static_assert(sizeof(PackMultiArgs) <= 4096, "kernel argument block");
+
+template <typename T>
+__global__ void __launch_bounds__(256) pack_multi_kernel(const PackMultiArgs m) {
+  __shared__ float tile[32][33];
+  int j = 0;
+  while (j + 1 < m.njobs && (int)blockIdx.x >= m.start[j + 1]) ++j;
+  const PackArgs& a = m.job[j];
+  const int local = blockIdx.x - m.start[j];
+  const int gx = (a.Kp + 31) >> 5;
+  const int by = local / gx;
+  pack_tile<T>(a, local - by * gx, by, tile);
 }
 
 // ============================================================================================
@@ -1609,6 +1640,25 @@ inline int eff_channels(int c, int cs, int vec) {
   return (cs % vec == 0 && ce <= cs) ? ce : 0;
 }
 
+// K order of the forward filter's taps.  Stride 2: the taps of one (kh & 1, kw & 1) parity class read the same quarter
+// of the input pixels (shifted by whole output pixels) and no other class touches that quarter, so walking K class by
+// class keeps a workgroup's live input at 1/4 of its slab for 4-9 consecutive taps: with 32 workgroups per XCD that
+// fits the 4 MB L2, where the natural row-major order re-fetched every pixel ~3x from beyond L2 (FETCH_SIZE 2.9x the
+// algorithmic bytes of the 192-row kernel).  Stride 1: natural order (all taps share the region anyway).
+inline int fwd_tap_order(const TdgConvDesc* d, int* ord) {
+  static const int enabled = getenv("TDG_TAPORDER") ? atoi(getenv("TDG_TAPORDER")) : 1;   // diagnostics: 0 = row-major
+  int n = 0;
+  if (d->stride == 2 && enabled) {
+    for (int pa = 0; pa < 2; ++pa)
+      for (int pb = 0; pb < 2; ++pb)
+        for (int kh = pa; kh < d->kh; kh += 2)
+          for (int kw = pb; kw < d->kw; kw += 2) ord[n++] = kh * d->kw + kw;
+  } else {
+    for (int t = 0; t < d->kh * d->kw; ++t) ord[n++] = t;
+  }
+  return n;
+}
+
 struct BwdClassPlan {
   int ntaps, nh, nw;
   int tap_ids[IG_MAX_TAPS];
@@ -1721,56 +1771,38 @@ size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d) {
   return total;
 }
 
-int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
-  int rc = validate_desc(d, "tdg_pack_filter_fwd");
-  if (rc) return rc;
+// ---- packing jobs ------------------------------------------------------------------------------------------------
+static void build_pack_fwd(const TdgConvDesc* d, const float* w, void* packed, PackArgs* a) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
   int ce = eff_channels(d->c, d->cs, vec);
   if (!ce) ce = d->c;
-  PackArgs a;
-  a.w = w;
-  a.out = packed;
-  a.rows = d->k;
-  a.ntaps = d->kh * d->kw;
-  a.C = d->c;
-  a.Ceff = ce;
-  a.Kp = (int)tdg_round_up((long long)a.ntaps * ce, bke);
-  a.stride_tap = d->c * d->k;
-  a.stride_row = 1;       // row = small-side channel (last master index)
-  a.stride_ch = d->k;     // K channel = big-side channel
-  for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = t;
-  dim3 grid(tdg_ceil_div(a.Kp, 32), tdg_ceil_div(a.rows, 32));
-  if (d->dtype == TDG_BF16)
-    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-  TDG_HIP_LAUNCH_CHECK("pack_filter_fwd");
-  return TDG_OK;
+  a->w = w;
+  a->out = packed;
+  a->rows = d->k;
+  a->ntaps = d->kh * d->kw;
+  a->C = d->c;
+  a->Ceff = ce;
+  a->Kp = (int)tdg_round_up((long long)a->ntaps * ce, bke);
+  a->stride_tap = d->c * d->k;
+  a->stride_row = 1;       // row = small-side channel (last master index)
+  a->stride_ch = d->k;     // K channel = big-side channel
+  int ord[IG_MAX_TAPS];
+  fwd_tap_order(d, ord);
+  for (int t = 0; t < a->ntaps; ++t) a->tap_ids[t] = (unsigned char)ord[t];
 }
 
-int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
-  int rc = validate_desc(d, "tdg_pack_filter_bwd");
-  if (rc) return rc;
+// one job per non-empty parity class; returns the count (the fused-class form is not handled here)
+static int build_pack_bwd(const TdgConvDesc* d, const float* w, void* packed, PackArgs* out) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
-  FusedPlan fp;
-  if (plan_bwd_fused(d, &fp)) {
-    FusedPackArgs a;
-    a.w = w;
-    a.out = static_cast<bf16_t*>(packed);
-    a.C = d->c; a.K = d->k; a.KH = d->kh; a.KW = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-    a.nhm = fp.nhm; a.nwm = fp.nwm; a.dh_min = fp.dh_min; a.dw_min = fp.dw_min; a.KP = fp.KP; a.wpitch = fp.wpitch;
-    hipLaunchKernelGGL(pack_fused_kernel, dim3(tdg_ceil_div(16 * fp.wpitch, 256)), dim3(256), 0, (hipStream_t)stream, a);
-    TDG_HIP_LAUNCH_CHECK("pack_filter_bwd(fused)");
-    return TDG_OK;
-  }
   int ke = eff_channels(d->k, d->ks, vec);
   if (!ke) ke = d->k;
   BwdClassPlan cls[IG_MAX_CLASSES];
   const int nc = plan_bwd_classes(d, cls);
   size_t off = 0;
+  int n = 0;
   for (int i = 0; i < nc; ++i) {
     if (cls[i].ntaps == 0) continue;
-    PackArgs a;
+    PackArgs& a = out[n++];
     a.w = w;
     a.out = static_cast<char*>(packed) + off;
     a.rows = d->c;
@@ -1781,16 +1813,111 @@ int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void
     a.stride_tap = d->c * d->k;
     a.stride_row = d->k;    // row = big-side channel
     a.stride_ch = 1;        // K channel = small-side channel (contiguous in the master)
-    for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = cls[i].tap_ids[t];
-    dim3 grid(tdg_ceil_div(a.Kp, 32), tdg_ceil_div(a.rows, 32));
-    if (d->dtype == TDG_BF16)
-      hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else
-      hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    TDG_HIP_LAUNCH_CHECK("pack_filter_bwd");
+    for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = (unsigned char)cls[i].tap_ids[t];
     off += (size_t)a.rows * a.Kp * es;
   }
+  return n;
+}
+
+static int launch_pack_one(const PackArgs& a, int dtype, hipStream_t s) {
+  dim3 grid(tdg_ceil_div(a.Kp, 32), tdg_ceil_div(a.rows, 32));
+  if (dtype == TDG_BF16)
+    hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(pack_filter_kernel<float>, grid, dim3(256), 0, s, a);
+  TDG_HIP_LAUNCH_CHECK("pack_filter");
   return TDG_OK;
+}
+
+static int launch_pack_fused(const TdgConvDesc* d, const FusedPlan& fp, const float* w, void* packed, hipStream_t s) {
+  FusedPackArgs a;
+  a.w = w;
+  a.out = static_cast<bf16_t*>(packed);
+  a.C = d->c; a.K = d->k; a.KH = d->kh; a.KW = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.nhm = fp.nhm; a.nwm = fp.nwm; a.dh_min = fp.dh_min; a.dw_min = fp.dw_min; a.KP = fp.KP; a.wpitch = fp.wpitch;
+  hipLaunchKernelGGL(pack_fused_kernel, dim3(tdg_ceil_div(16 * fp.wpitch, 256)), dim3(256), 0, s, a);
+  TDG_HIP_LAUNCH_CHECK("pack_filter_bwd(fused)");
+  return TDG_OK;
+}
+
+int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
+  int rc = validate_desc(d, "tdg_pack_filter_fwd");
+  if (rc) return rc;
+  TDG_CHECK_ARG(w && packed, "tdg_pack_filter_fwd: null pointer");
+  PackArgs a;
+  build_pack_fwd(d, w, packed, &a);
+  return launch_pack_one(a, d->dtype, (hipStream_t)stream);
+}
+
+int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
+  int rc = validate_desc(d, "tdg_pack_filter_bwd");
+  if (rc) return rc;
+  TDG_CHECK_ARG(w && packed, "tdg_pack_filter_bwd: null pointer");
+  FusedPlan fp;
+  if (plan_bwd_fused(d, &fp)) return launch_pack_fused(d, fp, w, packed, (hipStream_t)stream);
+  PackArgs a[IG_MAX_CLASSES];
+  const int n = build_pack_bwd(d, w, packed, a);
+  for (int i = 0; i < n; ++i) {
+    rc = launch_pack_one(a[i], d->dtype, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return TDG_OK;
+}
+
+int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
+  TDG_CHECK_ARG(jobs && n_jobs > 0, "tdg_pack_filters: no jobs");
+  const int dtype = jobs[0].desc.dtype;
+  static PackMultiArgs m;                       // 4 KB: built on the host, passed by value at launch (one host thread per GPU)
+  m.njobs = 0;
+  m.start[0] = 0;
+  auto flush = [&]() -> int {
+    if (m.njobs == 0) return TDG_OK;
+    if (dtype == TDG_BF16)
+      hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(m.start[m.njobs]), dim3(256), 0, (hipStream_t)stream, m);
+    else
+      hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(m.start[m.njobs]), dim3(256), 0, (hipStream_t)stream, m);
+    TDG_HIP_LAUNCH_CHECK("pack_filters");
+    m.njobs = 0;
+    return TDG_OK;
+  };
+  auto push = [&](const PackArgs& a) -> int {
+    if (m.njobs == PACK_MULTI_MAX) {
+      const int rc = flush();
+      if (rc) return rc;
+    }
+    m.job[m.njobs] = a;
+    m.start[m.njobs + 1] = m.start[m.njobs] + tdg_ceil_div(a.Kp, 32) * tdg_ceil_div(a.rows, 32);
+    ++m.njobs;
+    return TDG_OK;
+  };
+  for (int j = 0; j < n_jobs; ++j) {
+    const TdgConvDesc* d = &jobs[j].desc;
+    int rc = validate_desc(d, "tdg_pack_filters");
+    if (rc) return rc;
+    TDG_CHECK_ARG(d->dtype == dtype, "tdg_pack_filters: job %d has dtype %d, job 0 has %d", j, d->dtype, dtype);
+    TDG_CHECK_ARG(jobs[j].w, "tdg_pack_filters: job %d has no master filter", j);
+    if (jobs[j].packed_fwd) {
+      PackArgs a;
+      build_pack_fwd(d, jobs[j].w, jobs[j].packed_fwd, &a);
+      rc = push(a);
+      if (rc) return rc;
+    }
+    if (jobs[j].packed_bwd) {
+      FusedPlan fp;
+      if (plan_bwd_fused(d, &fp)) {
+        rc = launch_pack_fused(d, fp, jobs[j].w, jobs[j].packed_bwd, (hipStream_t)stream);
+        if (rc) return rc;
+      } else {
+        PackArgs a[IG_MAX_CLASSES];
+        const int n = build_pack_bwd(d, jobs[j].w, jobs[j].packed_bwd, a);
+        for (int i = 0; i < n; ++i) {
+          rc = push(a[i]);
+          if (rc) return rc;
+        }
+      }
+    }
+  }
+  return flush();
 }
 
 static void fill_epilogue(IgArgs& a, const TdgEpilogue* epi) {
@@ -1839,8 +1966,9 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   c.w_off_bytes = 0;
   c.fd_ghw = make_fastdiv(c.GH * c.GW);
   c.fd_gw = make_fastdiv(c.GW);
-  for (int kh = 0; kh < d->kh; ++kh)
-    for (int kw = 0; kw < d->kw; ++kw) c.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
+  int ord[IG_MAX_TAPS];
+  fwd_tap_order(d, ord);
+  for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(ord[t] / d->kw - d->pad_t, ord[t] % d->kw - d->pad_l);
   c.nh = d->kh; c.nw = d->kw; c.dh0 = -d->pad_t; c.dw0 = -d->pad_l; c.sh = c.sw = 1;
   c.fd_nw = make_fastdiv(c.nw);
   const int bn = pick_bn(d->k);
@@ -1952,7 +2080,23 @@ static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   const int M = n_images * d->oh * d->ow;
   const bool dma = wgrad_use_dma(d);
   const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, dma ? 256 : 128) * tdg_ceil_div(d->k, pick_bn(d->k));
-  int want = dma ? 512 / tiles : tdg_ceil_div(768, tiles);   // DMA: ~2 rounds of one workgroup per CU; else ~3 per CU
+  int want = tdg_ceil_div(768, tiles);                  // register-staged kernel: ~3 workgroups per CU
+  if (dma) {
+    // one workgroup per CU: the fewest splits (each costs an f32 slab written and re-read) whose last round of
+    // 256 workgroups is within 10 % of the best fill any split count up to 16 reaches
+    static const int force = getenv("TDG_WSPLIT") ? atoi(getenv("TDG_WSPLIT")) : 0;   // diagnostics
+    double best = 0.0;
+    for (int sp = 1; sp <= 16; ++sp) {
+      const double fill = (double)tiles * sp / (256.0 * tdg_ceil_div((long long)tiles * sp, 256));
+      best = fill > best ? fill : best;
+    }
+    want = 16;
+    for (int sp = 1; sp <= 16; ++sp) {
+      const double fill = (double)tiles * sp / (256.0 * tdg_ceil_div((long long)tiles * sp, 256));
+      if (fill >= 0.9 * best) { want = sp; break; }
+    }
+    if (force) want = force;
+  }
   const int max_split = tdg_ceil_div(M, mr * 4);        // keep >= 4 steps per split
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;

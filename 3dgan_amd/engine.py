@@ -192,6 +192,7 @@ class SeqNet:
                  tangent_capacity=0, ws=None, out_act=None, out_grad=None):
         self.net, self.cap, self.dtype, self.device, self.store = net, capacity, dtype, device, store
         self.ws = ws or K.Workspace(device)
+        self._pack_jobs = None
         self.n_bn_passes = n_bn_passes
         h, w, c = in_shape
         self.x = K.Act(capacity, h, w, c, dtype, device)                   # net input
@@ -275,9 +276,12 @@ class SeqNet:
 
     def repack(self):
         """Refresh the packed GEMM operands from the f32 masters (after every optimizer step)."""
-        for L in self.layers:
-            if not L.rowdot:
-                L.conv.pack(self.store[L.wname])
+        if self._pack_jobs is None:
+            # masters and packed buffers never move, so the job table is built once
+            jl = [L.conv.pack_job(self.store[L.wname]) for L in self.layers if not L.rowdot]
+            self._pack_jobs = K.make_pack_jobs(jl) if jl else ()
+        if len(self._pack_jobs):
+            K.pack_all(self._pack_jobs)
 
     # -- forward -----------------------------------------------------------------------------------
     def forward(self, img0, n, bn_pass=0):

@@ -125,6 +125,15 @@ class GemmTimer:
 TIMER = None       # set to a GemmTimer to time conv GEMM launches
 
 
+def pack_all(jobs):
+    """All filters of a network in one library call (tdg_pack_filters); `jobs` is a ctypes array of PackJob."""
+    _lib.call('tdg_pack_filters', jobs, len(jobs), stream())
+
+
+def make_pack_jobs(job_list):
+    return (_lib.PackJob * len(job_list))(*job_list)
+
+
 class Conv:
     """One strided conv of the model: owns the packed filter operands and the split-K
     workspace; exposes the three GEMM forms of include/tdg.h."""
@@ -155,6 +164,10 @@ class Conv:
             _lib.call('tdg_pack_filter_fwd', C.byref(self.desc), ptr(w), ptr(self.w_fwd), stream())
         if bwd:
             _lib.call('tdg_pack_filter_bwd', C.byref(self.desc), ptr(w), ptr(self.w_bwd), stream())
+
+    def pack_job(self, w, fwd=True, bwd=True):
+        """The TdgPackJob equivalent of pack(w, fwd, bwd), for pack_all()."""
+        return _lib.PackJob(self.desc, ptr(w), ptr(self.w_fwd) if fwd else None, ptr(self.w_bwd) if bwd else None)
 
     def flops(self, n_images):
         """Algorithmic FLOPs of any of the three GEMM forms on n_images (2 x MACs, padding taps counted)."""

@@ -371,10 +371,11 @@ class UNet:
                     self.store[net.var_name(l, which)].copy_(torch.randn(shape, generator=gen) * 0.02)
 
     def repack(self):
-        for k in range(1, 9):
-            self.e_conv[k].pack(self.store[self.enet.var_name(self.enet.layers[k - 1], 'weights')])
-        for i in range(1, 9):
-            self.d_conv[i].pack(self.store[self.dnet.var_name(self.dnet.layers[i - 1], 'weights')])
+        if getattr(self, '_pack_jobs', None) is None:
+            jl = [self.e_conv[k].pack_job(self.store[self.enet.var_name(self.enet.layers[k - 1], 'weights')]) for k in range(1, 9)]
+            jl += [self.d_conv[i].pack_job(self.store[self.dnet.var_name(self.dnet.layers[i - 1], 'weights')]) for i in range(1, 9)]
+            self._pack_jobs = K.make_pack_jobs(jl)
+        K.pack_all(self._pack_jobs)
 
     # ---- forward: G(x) into g_out ---------------------------------------------------------------------------------
     def forward(self):

@@ -88,6 +88,18 @@ size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d);
 int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream);
 int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void* stream);
 
+/* Every filter of a network in one call (after an optimizer step the reference's variables change all at
+ * once: tf.train.Optimizer.apply_gradients, models/gan.py:80-81): same results as calling the two functions
+ * above per job, in as few launches as the jobs fit.  All jobs must share one dtype.  A null destination
+ * skips that form. */
+typedef struct TdgPackJob {
+  TdgConvDesc desc;
+  const float* w;          /* f32 master filter [kh][kw][c][k] */
+  void* packed_fwd;
+  void* packed_bwd;
+} TdgPackJob;
+int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream);
+
 /* ---- conv GEMMs -------------------------------------------------------------------------
  * tdg_conv2d_fwd      : y = epi(conv2d(x, W))            tf.nn.conv2d, ops/layers.py:101;
  *                       also d(conv2d_transpose)/d(input) (autodiff of ops/layers.py:142)
