@@ -498,7 +498,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   constexpr int NIB = LD::NIB;                      // B wave-instructions per step (8 rows each)
   constexpr int NBJ = LD::NBJ;                      // per wave
   constexpr int STAGE = (BM + BNL) * IG_BKB;
-  constexpr int ILV = NS == 3 ? 2 : 1;              // tiles between loader pieces: a 2-stage ring wants them early
+  // tiles between loader pieces: a 2-stage ring wants them early, a 3-stage ring spread over the step
+  constexpr int ILV = NS == 2 ? 1 : ((2 * ((BN / 16 + 1) / 2) - 1) / (LD::NP - 1) >= 2 ? 2 : 1);
   static_assert(BN % 16 == 0, "tile config");
   using Frag = typename Mma<T>::frag;
 
@@ -610,7 +611,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     // barrier.  Raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA.
     auto wait_barrier = [&](bool more_in_flight) {
       if (more_in_flight) {
-        static_assert(LD::NP >= 5 && LD::NP <= 8, "add the immediate");
+        static_assert(LD::NP >= 4 && LD::NP <= 8, "add the immediate");
+        if constexpr (LD::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr (LD::NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         if constexpr (LD::NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         if constexpr (LD::NP == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
@@ -1251,6 +1253,31 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(const float* __restric
     if (4 * i + e < n) dw[4 * i + e] = (beta != 0.f ? beta * dw[4 * i + e] : 0.f) + s[e];
 }
 
+// few slabs (<= 8): one 16-byte column per thread, every slab's load in flight before the sum (z ascending: the same
+// fixed order).  The 16-z-lane kernel above leaves 13 of 16 lanes idle at 3 slabs (1.8 TB/s).
+__global__ void __launch_bounds__(256) slab_reduce_few_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                             size_t n, int nsplit, size_t stride, float beta) {
+  const size_t n4 = (n + 3) >> 2;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v[8];
+#pragma unroll
+  for (int z = 0; z < 8; ++z)
+    v[z] = z < nsplit ? *reinterpret_cast<const f32x4*>(slabs + (size_t)z * stride + 4 * i) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 s = v[0];
+#pragma unroll
+  for (int z = 1; z < 8; ++z) s += v[z];
+  if (4 * i + 3 < n) {
+    f32x4 o = s;
+    if (beta != 0.f) o += beta * *reinterpret_cast<const f32x4*>(dw + 4 * i);
+    *reinterpret_cast<f32x4*>(dw + 4 * i) = o;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (4 * i + e < n) dw[4 * i + e] = (beta != 0.f ? beta * dw[4 * i + e] : 0.f) + s[e];
+  }
+}
+
 // ============================================================================================
 // filter packing: f32 master [taps][Cdim][Kdim] -> packed [rows][Kp] (dtype T), zero padded
 //   element (row r, tap index ti, channel c) = w[tap_ids[ti] * stride_tap + r*stride_row + c*stride_ch]
@@ -1506,9 +1533,9 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
   }
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
   hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS>), grid, block, lds, s, a);
-  tdg_note_kernel(BM == 256 ? (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,256,208>" : "igemm_fwd_dma_kernel<f32,256,208>")
-                  : BM == 192 ? (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,192,208>" : "igemm_fwd_dma_kernel<f32,192,208>")
-                              : (sizeof(T) == 2 ? "igemm_fwd_dma_kernel<bf16,128,208>" : "igemm_fwd_dma_kernel<f32,128,208>"));
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_dma_kernel<%s,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN);
+  tdg_note_kernel(name);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
 }
@@ -1549,6 +1576,12 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     if (bm == 128) return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
     if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
     return launch_fwd_dma<T, 256, 208, 2>(a, mmax, s);
+  }
+  // 65..112 columns (the generator's 100-channel layers): the same kernel with a 7-tile-wide column tile
+  if (veca && bn == 128 && a.N <= 112 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
+    const long long t256 = (long long)a.nclasses * tdg_ceil_div(mmax, 256), t128 = (long long)a.nclasses * tdg_ceil_div(mmax, 128);
+    const double c256 = (double)tdg_ceil_div(t256, 256) * 256, c128 = (double)tdg_ceil_div(t128, 256) * 128 / 0.85;
+    return c128 < c256 ? launch_fwd_dma<T, 128, 112, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 112, 3>(a, mmax, s);
   }
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
@@ -2161,9 +2194,14 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
   const size_t n = (size_t)a.ntaps * d->c * d->k;
-  const int blocks = (int)(((n + 3) / 4 + 15) / 16);
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.slabs, dw, n, a.nsplit,
-                     (size_t)a.slab_stride, beta);
+  if (a.nsplit <= 8 && ((uintptr_t)dw & 15) == 0) {
+    hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.slabs,
+                       dw, n, a.nsplit, (size_t)a.slab_stride, beta);
+  } else {
+    const int blocks = (int)(((n + 3) / 4 + 15) / 16);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.slabs, dw, n, a.nsplit,
+                       (size_t)a.slab_stride, beta);
+  }
   TDG_HIP_LAUNCH_CHECK("slab_reduce");
   return TDG_OK;
 }
