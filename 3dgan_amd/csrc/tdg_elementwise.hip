@@ -192,17 +192,27 @@ struct FinArgs {
   float* out1;          // bwd: mean sums [2][C] for the apply pass
   float beta_acc;
 };
-// 32 channels x 8 partial lanes per block; fixed summation order (deterministic)
+// 8 channels x 32 partial lanes per block (C/8 blocks: enough workgroups and short enough per-thread chains for up to
+// 1024 row blocks); fixed summation order (deterministic)
+#define FIN_CH 8
 template <typename T, int MODE>
 __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
-  __shared__ float sh[2][8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  __shared__ float sh[2][32][FIN_CH];
+  const int tx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + tx;
   float s0 = 0.f, s1 = 0.f;
   if (c < a.C)
-    for (int b = ty; b < a.nblk; b += 8) {
-      s0 += a.partial[((size_t)b * 2 + 0) * a.C + c];
-      s1 += a.partial[((size_t)b * 2 + 1) * a.C + c];
+    for (int b0 = ty; b0 < a.nblk; b0 += 4 * 32) {
+      float p0[4], p1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = b0 + 32 * u;
+        const bool ok = b < a.nblk;
+        p0[u] = ok ? a.partial[((size_t)b * 2 + 0) * a.C + c] : 0.f;
+        p1[u] = (ok && MODE != FIN_ACC) ? a.partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += p0[u]; s1 += p1[u]; }
     }
   sh[0][ty][tx] = s0;
   sh[1][ty][tx] = s1;
@@ -210,7 +220,7 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   if (ty != 0 || c >= a.C) return;
   s0 = s1 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
+  for (int k = 0; k < 32; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
   const float inv = 1.f / (float)a.rows;
   if (MODE == FIN_BN_STATS) {
     const float pivot = to_f32<T>(static_cast<const T*>(a.x0)[c]);
@@ -326,7 +336,7 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_STATS>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + 31) / 32), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
     if (ga.vw == 4)
       hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
                          leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
@@ -358,7 +368,7 @@ extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + 31) / 32), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
     if (ga.vw == 4)
       hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
                          static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
@@ -383,7 +393,7 @@ extern "C" int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_SUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + 31) / 32), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
   })
   TDG_HIP_LAUNCH_CHECK("bias_grad");
   return TDG_OK;
@@ -402,7 +412,7 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_WSUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + 31) / 32), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
   })
   TDG_HIP_LAUNCH_CHECK("colsum_weighted");
   return TDG_OK;
