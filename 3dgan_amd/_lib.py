@@ -33,6 +33,11 @@ class PackJob(C.Structure):
     _fields_ = [('desc', ConvDesc), ('w', C.c_void_p), ('packed_fwd', C.c_void_p), ('packed_bwd', C.c_void_p)]
 
 
+class LaunchRecord(C.Structure):
+    """TdgLaunchRecord (include/tdg.h)."""
+    _fields_ = [('kernel', C.c_char * 64), ('ms', C.c_double), ('flops', C.c_double)]
+
+
 _vp, _i, _f, _sz, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 _PD, _PE = C.POINTER(ConvDesc), C.POINTER(Epilogue)
 
@@ -41,6 +46,8 @@ SIGNATURES = {
     'tdg_last_error': (C.c_char_p, []),
     'tdg_version': (_i, []),
     'tdg_last_kernel': (C.c_char_p, []),
+    'tdg_timing_begin': (_i, []),
+    'tdg_timing_end': (_i, [C.POINTER(LaunchRecord), _i, C.POINTER(_i)]),
     'tdg_packed_filter_fwd_bytes': (_sz, [_PD]),
     'tdg_packed_filter_bwd_bytes': (_sz, [_PD]),
     'tdg_pack_filter_fwd': (_i, [_PD, _vp, _vp, _vp]),

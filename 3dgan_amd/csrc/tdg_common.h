@@ -19,6 +19,8 @@ typedef __attribute__((ext_vector_type(2))) int i32x2;
 // ---------------------------------------------------------------------------- errors
 void tdg_set_error(const char* fmt, ...);
 void tdg_note_kernel(const char* name);
+void tdg_timing_start(const char* name, double flops, hipStream_t s);   // no-ops unless tdg_timing_begin() is active
+void tdg_timing_stop(hipStream_t s);
 
 #define TDG_CHECK_ARG(cond, ...)   \
   do {                             \

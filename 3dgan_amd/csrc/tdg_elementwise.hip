@@ -20,6 +20,59 @@ static thread_local const char* g_last_kernel = "";
 void tdg_note_kernel(const char* name) { g_last_kernel = name; }
 extern "C" const char* tdg_last_kernel(void) { return g_last_kernel; }
 
+// ---------------------------------------------------------------------------- per-launch timing (diagnostics)
+// HIP events around every conv GEMM kernel launch, on the stream the kernel is launched on.  Off unless
+// tdg_timing_begin() was called; not usable while a stream capture is in progress.
+#include <vector>
+struct TimingSlot { const char* name; double flops; hipEvent_t e0, e1; };
+static std::vector<TimingSlot> g_slots;
+static int g_timing_on = 0, g_timing_n = 0;
+bool tdg_timing_enabled() { return g_timing_on != 0; }
+void tdg_timing_start(const char* name, double flops, hipStream_t s) {
+  if (!g_timing_on) return;
+  if (g_timing_n == (int)g_slots.size()) {
+    TimingSlot t;
+    t.name = ""; t.flops = 0;
+    (void)hipEventCreate(&t.e0);
+    (void)hipEventCreate(&t.e1);
+    g_slots.push_back(t);
+  }
+  TimingSlot& t = g_slots[g_timing_n];
+  t.name = name;
+  t.flops = flops;
+  (void)hipEventRecord(t.e0, s);
+}
+void tdg_timing_stop(hipStream_t s) {
+  if (!g_timing_on) return;
+  (void)hipEventRecord(g_slots[g_timing_n].e1, s);
+  ++g_timing_n;
+}
+extern "C" int tdg_timing_begin(void) {
+  g_timing_on = 1;
+  g_timing_n = 0;
+  return TDG_OK;
+}
+extern "C" int tdg_timing_end(TdgLaunchRecord* out, int capacity, int* count) {
+  g_timing_on = 0;
+  TDG_CHECK_ARG(count != nullptr, "tdg_timing_end: null count");
+  int n = 0;
+  for (int i = 0; i < g_timing_n; ++i) {
+    if (hipEventSynchronize(g_slots[i].e1) != hipSuccess) { tdg_set_error("tdg_timing_end: event sync failed"); return TDG_EHIP; }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, g_slots[i].e0, g_slots[i].e1);
+    if (out && n < capacity) {
+      strncpy(out[n].kernel, g_slots[i].name, sizeof(out[n].kernel) - 1);
+      out[n].kernel[sizeof(out[n].kernel) - 1] = 0;
+      out[n].ms = ms;
+      out[n].flops = g_slots[i].flops;
+    }
+    ++n;
+  }
+  *count = n;
+  g_timing_n = 0;
+  return TDG_OK;
+}
+
 #define DISPATCH_T(dtype, ...)                  \
   if ((dtype) == TDG_BF16) {                    \
     using T = bf16_t;                           \

@@ -38,6 +38,7 @@ struct IgArgs {
   int act, mask_mode, accumulate;
   float leak;
   int ntiles_n, ntiles_m_max, nclasses;
+  int n_begin;           // first output column of this launch (a problem's columns may be split over launches)
   unsigned long long* stamps;  // diagnostic build (-DTDG_STAMPS) only: per-wave cycle sums; null otherwise
   int debug;             // TDG_DEBUG_ABLATE (diagnostics only): 1 no global loads in loop, 2 + no LDS stores, 3 no MFMA
   IgClass cls[IG_MAX_CLASSES];

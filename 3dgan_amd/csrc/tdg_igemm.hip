@@ -513,7 +513,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   const int tile_n = bid - tile_m * args.ntiles_n;
   const int M = cl.M;
   if (tile_m * BM >= M) return;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int par = wave & 1, wh = wave >> 1;
@@ -1493,6 +1493,8 @@ __global__ void __launch_bounds__(256) pack_fused_kernel(const FusedPackArgs a) 
 // ============================================================================================
 namespace {
 
+thread_local double t_flops = 0.0;   // algorithmic FLOPs of the entry-point call being dispatched (for tdg_timing_*)
+
 struct TileCfg { int bm, bn; };
 
 inline int pick_bn(int n) {
@@ -1506,23 +1508,24 @@ template <typename T, int BM, int BN, int WGM, int WGN>
 int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStream_t s) {
   const size_t lds = (size_t)(BM + BN) * IG_BKB + IG_MAX_TAPS * sizeof(int);
   dim3 grid(grid_x, 1, nclasses), block(256);
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_kernel<%s,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN);
+  tdg_note_kernel(name);
+  tdg_timing_start(name, t_flops, s);
   if (veca)
     hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, true>), grid, block, lds, s, a);
   else
     hipLaunchKernelGGL((igemm_fwd_kernel<T, BM, BN, WGM, WGN, false>), grid, block, lds, s, a);
-  {
-    static const char* names[2][4] = {{"igemm_fwd_kernel<f32,128,16>", "igemm_fwd_kernel<f32,128,64>", "igemm_fwd_kernel<f32,128,128>", "igemm_fwd_kernel<f32,128,208>"},
-                                      {"igemm_fwd_kernel<bf16,128,16>", "igemm_fwd_kernel<bf16,128,64>", "igemm_fwd_kernel<bf16,128,128>", "igemm_fwd_kernel<bf16,128,208>"}};
-    tdg_note_kernel(BM == 64 ? (sizeof(T) == 2 ? "igemm_fwd_kernel<bf16,64,208>" : "igemm_fwd_kernel<f32,64,208>")
-                             : names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
-  }
+  tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd");
   return TDG_OK;
 }
 
+// columns [n_begin, n_begin + ntiles_n * BN) of the problem (clipped to N)
 template <typename T, int BM, int BN, int NS>
-int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
-  a.ntiles_n = tdg_ceil_div(a.N, BN);
+int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntiles_n = -1) {
+  a.n_begin = n_begin;
+  a.ntiles_n = ntiles_n < 0 ? tdg_ceil_div(a.N, BN) : ntiles_n;
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
   const size_t lds = NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
@@ -1531,11 +1534,14 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
-  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS>), grid, block, lds, s, a);
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_dma_kernel<%s,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_dma_kernel<%s,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, NS);
   tdg_note_kernel(name);
+  const int n_end = n_begin + a.ntiles_n * BN < a.N ? n_begin + a.ntiles_n * BN : a.N;
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  tdg_timing_start(name, t_flops * (double)(n_end - n_begin) / (double)a.N, s);
+  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS>), grid, block, lds, s, a);
+  tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
 }
@@ -1557,7 +1563,10 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   // register-staged one even when the grid does not fill the chip)
   if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
     // one 8-wave workgroup per CU.  Row tiles: 256 (2-stage LDS ring), 192 and 128 (3-stage ring, loads two
-    // steps ahead).  Cost model: rounds of 256 workgroups x rows per tile / measured relative efficiency.
+    // steps ahead).  (Covering 400 = 208 + 192 / 800 = 2 x 208 + 2 x 192 columns exactly with a second launch of
+    // 192-wide tiles -- 26 / 52 column tiles of 16 instead of 28 / 56 -- was measured: -1..-4 % on the 1536-image
+    // GEMMs, +9 % on c3 backward-data and up to +70 % wherever a launch no longer fills the chip.  Not kept.)
+    // Cost model for the row tile: rounds of 256 workgroups x rows per tile / measured relative efficiency.
     const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
     static const int force = getenv("TDG_DMA_BM") ? atoi(getenv("TDG_DMA_BM")) : 0;   // diagnostics
     const int bms[3] = {256, 192, 128};
@@ -1607,15 +1616,15 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
   constexpr int MR = WgGeom<T>::MR;
   const size_t lds = (size_t)MR * (WgGeom<T>::pitch(BKK) + WgGeom<T>::pitch(BN)) + IG_MAX_TAPS * sizeof(int);
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(256);
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_kernel<%s,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BKK, BN);
+  tdg_note_kernel(name);
+  tdg_timing_start(name, t_flops, s);
   if (veca)
     hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, true>), grid, block, lds, s, a);
   else
     hipLaunchKernelGGL((igemm_wgrad_kernel<T, BKK, BN, WGK, WGN, false>), grid, block, lds, s, a);
-  {
-    static const char* names[2][4] = {{"igemm_wgrad_kernel<f32,128,16>", "igemm_wgrad_kernel<f32,128,64>", "igemm_wgrad_kernel<f32,128,128>", "igemm_wgrad_kernel<f32,128,208>"},
-                                      {"igemm_wgrad_kernel<bf16,128,16>", "igemm_wgrad_kernel<bf16,128,64>", "igemm_wgrad_kernel<bf16,128,128>", "igemm_wgrad_kernel<bf16,128,208>"}};
-    tdg_note_kernel(names[sizeof(T) == 2][BN == 16 ? 0 : BN == 64 ? 1 : BN == 128 ? 2 : 3]);
-  }
+  tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad");
   return TDG_OK;
 }
@@ -1628,8 +1637,10 @@ int launch_wgrad_dma208(WgArgs& a, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
-  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<208>), grid, block, lds, s, a);
   tdg_note_kernel("igemm_wgrad_dma_kernel<bf16,256,208>");
+  tdg_timing_start("igemm_wgrad_dma_kernel<bf16,256,208>", t_flops, s);
+  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<208>), grid, block, lds, s, a);
+  tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad_dma");
   return TDG_OK;
 }
@@ -1644,6 +1655,10 @@ int launch_wgrad(WgArgs& a, bool veca, int bn, hipStream_t s) {
   }
   tdg_set_error("igemm_wgrad: no tile config for BN=%d", bn);
   return TDG_EUNSUPPORTED;
+}
+
+inline double conv_flops(const TdgConvDesc* d, int n_images) {
+  return 2.0 * n_images * d->oh * d->ow * d->kh * d->kw * (double)d->c * d->k;
 }
 
 inline short pack_tap(int dh, int dw) { return (short)((dh & 0xff) | ((dw & 0xff) << 8)); }
@@ -2005,6 +2020,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   c.nh = d->kh; c.nw = d->kw; c.dh0 = -d->pad_t; c.dw0 = -d->pad_l; c.sh = c.sw = 1;
   c.fd_nw = make_fastdiv(c.nw);
   const int bn = pick_bn(d->k);
+  t_flops = conv_flops(d, n_images);
   return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
                               : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
 }
@@ -2046,8 +2062,10 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
-    hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr), dim3(512), fp.lds, (hipStream_t)stream, f);
     tdg_note_kernel("bwd_fused_kernel<bf16>");
+    tdg_timing_start("bwd_fused_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
+    hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr), dim3(512), fp.lds, (hipStream_t)stream, f);
+    tdg_timing_stop((hipStream_t)stream);
     TDG_HIP_LAUNCH_CHECK("bwd_fused");
     return TDG_OK;
   }
@@ -2092,6 +2110,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     off += (unsigned)((size_t)d->c * Kp * es);
   }
   const int bn = pick_bn(d->c);
+  t_flops = conv_flops(d, n_images);
   return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
                               : launch_fwd<float>(a, veca, bn, (hipStream_t)stream);
 }
@@ -2189,11 +2208,13 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
   a.ntiles_k = tdg_ceil_div(a.KK, dma ? 256 : 128);
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
+  t_flops = conv_flops(d, n_images);
   rc = dma ? launch_wgrad_dma208(a, (hipStream_t)stream)
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
   const size_t n = (size_t)a.ntaps * d->c * d->k;
+  tdg_timing_start("slab_reduce", 0.0, (hipStream_t)stream);
   if (a.nsplit <= 8 && ((uintptr_t)dw & 15) == 0) {
     hipLaunchKernelGGL(slab_reduce_few_kernel, dim3((unsigned)(((n + 3) / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a.slabs,
                        dw, n, a.nsplit, (size_t)a.slab_stride, beta);
@@ -2202,6 +2223,7 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a.slabs, dw, n, a.nsplit,
                        (size_t)a.slab_stride, beta);
   }
+  tdg_timing_stop((hipStream_t)stream);
   TDG_HIP_LAUNCH_CHECK("slab_reduce");
   return TDG_OK;
 }

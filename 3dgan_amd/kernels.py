@@ -125,6 +125,19 @@ class GemmTimer:
 TIMER = None       # set to a GemmTimer to time conv GEMM launches
 
 
+def timing_begin():
+    """Start the library's per-launch HIP-event timing of conv GEMM kernels (diagnostics; not during graph capture)."""
+    _lib.call('tdg_timing_begin')
+
+
+def timing_end(capacity=65536):
+    """Stop it; returns [(kernel, ms, flops)] with one entry per kernel launch since timing_begin()."""
+    buf = (_lib.LaunchRecord * capacity)()
+    n = C.c_int(0)
+    _lib.call('tdg_timing_end', buf, capacity, C.byref(n))
+    return [(buf[i].kernel.decode(), buf[i].ms, buf[i].flops) for i in range(min(n.value, capacity))]
+
+
 def pack_all(jobs):
     """All filters of a network in one library call (tdg_pack_filters); `jobs` is a ctypes array of PackJob."""
     _lib.call('tdg_pack_filters', jobs, len(jobs), stream())

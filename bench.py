@@ -152,11 +152,12 @@ def main():
         rep.use_graphs = False
         rep.train_func()
         if sess.rank == 0:
-            timer = K.TIMER = K.GemmTimer()
+            K.timing_begin()                      # HIP events around every conv GEMM kernel launch, inside the library
         for _ in range(args.timer_steps):
             rep.train_func()
         sync()
-        K.TIMER = None
+        if sess.rank == 0:
+            timer = K.timing_end()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=sess.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,31 +179,34 @@ def main():
                        'step_tflops': value / args.gpus * GFLOP_PER_IMAGE_ITERATION / 1e3,
                        'final_losses': status},
         }
-        if timer is not None:
-            summ = timer.summary()
-            sym = timer.summary(by_symbol=True)
-            # dominant kernel = the GEMM kernel symbol (as rocprofv3 names it) with the largest total time
-            kind, (n, tot_ms, fl) = max(sym.items(), key=lambda kv: kv[1][1])
+        if timer:
+            sym = {}
+            for name, kms, fl in timer:
+                e = sym.setdefault(name, [0, 0.0, 0.0])
+                e[0] += 1
+                e[1] += kms
+                e[2] += fl
+            gemm = {k: v for k, v in sym.items() if v[2] > 0}
+            # dominant kernel = the GEMM kernel symbol with the largest total time
+            kind, (n, tot_ms, fl) = max(gemm.items(), key=lambda kv: kv[1][1])
             achieved = fl / (tot_ms * 1e-3) / 1e12
-            gemm_ms = sum(v[1] for v in summ.values())
-            gemm_fl = sum(v[2] for v in summ.values())
+            gemm_ms = sum(v[1] for v in gemm.values())
+            gemm_fl = sum(v[2] for v in gemm.values())
             traffic, traffic_src = pmc_traffic(kind)
             out['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[args.dtype], 'unit': 'TFLOP/s',
                                'frac': achieved / PEAK_TFLOPS[args.dtype], 'traffic': traffic, 'traffic_source': traffic_src,
                                'kernel': kind, 'launches': n, 'avg_launch_ms': tot_ms / n,
-                               'measured': 'HIP events around every conv GEMM launch in %d instrumented eager steps run '
-                                           'directly after the timed region (hipGraph replay hides launches from events); '
-                                           'achieved = sum of algorithmic FLOPs / sum of durations over all launches of this '
-                                           'kernel symbol' % args.timer_steps,
+                               'flop_per_launch': fl / n,
+                               'measured': 'HIP events recorded by the library around every conv GEMM kernel launch (on the launch '
+                                           'stream) in %d instrumented eager steps run directly after the timed region (hipGraph '
+                                           'replay hides launches from events); achieved = sum of algorithmic FLOPs / sum of '
+                                           'durations over all launches of this kernel' % args.timer_steps,
                                'all_conv_gemms': {'ms_per_step': gemm_ms / args.timer_steps,
                                                   'tflops': gemm_fl / (gemm_ms * 1e-3) / 1e12,
                                                   'share_of_step': gemm_ms / args.timer_steps / ms},
-                               'per_symbol': {k: {'launches': v[0], 'avg_ms': round(v[1] / v[0], 4),
+                               'per_kernel': {k: {'launches': v[0], 'avg_ms': round(v[1] / v[0], 4),
                                                   'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
-                                              for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])},
-                               'per_shape': {k: {'launches': v[0], 'avg_ms': round(v[1] / v[0], 4),
-                                                 'tflops': round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
-                                             for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1])}}
+                                              for k, v in sorted(sym.items(), key=lambda kv: -kv[1][1])}}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))

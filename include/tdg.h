@@ -79,6 +79,19 @@ int tdg_version(void);
  * lets a caller attribute HIP-event timings to the kernel symbols rocprofv3 reports). */
 const char* tdg_last_kernel(void);
 
+/* Diagnostics (bench.py's roofline leg): between tdg_timing_begin() and tdg_timing_end() every conv GEMM kernel
+ * launch is bracketed by HIP events on its own stream; tdg_timing_end() waits for them and returns one record per
+ * launch: the kernel (as rocprofv3 names it, template arguments included), its duration and the algorithmic FLOPs
+ * of the columns/rows it covered.  `count` receives the number of launches even when it exceeds `capacity`.
+ * Not for use during stream capture. */
+typedef struct TdgLaunchRecord {
+  char kernel[64];
+  double ms;
+  double flops;
+} TdgLaunchRecord;
+int tdg_timing_begin(void);
+int tdg_timing_end(TdgLaunchRecord* out, int capacity, int* count);
+
 /* ---- filter packing: f32 master -> GEMM operand layout in desc.dtype ------------------
  * FWD form  : rows = k (small-side channels), K = (tap, c)        -> used by tdg_conv2d_fwd
  * BWD form  : per output-parity class, rows = c, K = (tap', k)    -> used by tdg_conv2d_bwd_data
