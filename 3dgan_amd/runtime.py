@@ -26,7 +26,7 @@ class Session:
         if device is None:
             if not torch.cuda.is_available():
                 raise _lib.TdgError('no MI355X visible: the 3dgan_amd hot path has no CPU fallback')
-            device = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+            device = local_device()
         self.device = torch.device(device)
         if self.device.type == 'cuda':
             torch.cuda.set_device(self.device)
@@ -96,13 +96,22 @@ class Session:
                     raise FloatingPointError('%s: gradient of %s has NaN or Inf' % (what, name))
 
 
+def local_device():
+    """cuda:<LOCAL_RANK>; ranks beyond the visible devices wrap around (single-GPU rehearsals of the N > 1 path only)."""
+    n = torch.cuda.device_count()
+    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(n, 1))
+
+
 def init_distributed(backend=None):
-    """Join the process group when launched by torch.distributed.run (RANK/WORLD_SIZE set)."""
+    """Join the process group when launched by torch.distributed.run (RANK/WORLD_SIZE set): one process per GPU,
+    backend "nccl" (= RCCL over xGMI); TDG_DIST_BACKEND=gloo rehearses the same code path without RCCL."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
     if ws > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('TDG_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_device())    # before the communicator is created
         dist.init_process_group(backend=backend)
     return ws
 
