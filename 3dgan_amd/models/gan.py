@@ -190,6 +190,17 @@ class GanReplica:
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246
         self.G.forward(0, self.B)                                      # g lands in D.x slot 1
 
+    def samples(self, n):
+        """(inputs, fake) as float32 NHWC in [-1, 1]: the first n images of the staged real batch and of a fresh
+        generator pass (models/gan.py:99-100 `x[0:args.examples]`, `g[0:args.examples]`)."""
+        h, w, c = self.args.image_shape
+        n = min(n, self.B)
+        self._rescale_real()
+        self._generate()
+        view = self.D.x.buf[:2 * self.B * h * w * self.D.x.cs].view(2, self.B, h, w, self.D.x.cs)
+        both = view[:, :n, :, :, :c].float().cpu().numpy()
+        return both[0], both[1]
+
     def _interpolate(self):
         """models/gan.py:224-226 into slot 2."""
         B = self.B

@@ -151,3 +151,40 @@ def test_param_store_checkpoint_round_trip(tmp_path):
     ck.restore(path, rep, sess)
     assert torch.equal(s['generator/vars/fc1/weights'], torch.arange(15.).view(3, 5))
     assert (opt.t, sess.global_step, sess.global_epoch) == (7, 12, 2)
+
+
+def test_montage_layout_and_png_roundtrip(tmp_path):
+    """ops/summaries.py:97-124: image j*m + r lands at block row j, block column r; PNG bytes decode back."""
+    import struct
+    import zlib
+    S = pkg('summaries')
+    m, n, H, W, C = 4, 2, 3, 5, 3
+    x = np.arange(m * n * H * W * C, dtype=np.float32).reshape(m * n, H, W, C)
+    out = S.montage(x, m, n)
+    assert out.shape == (n * H, m * W, C)
+    for j in range(n):
+        for r in range(m):
+            assert np.array_equal(out[j * H:(j + 1) * H, r * W:(r + 1) * W], x[j * m + r])
+    assert S.factorization(64) == (8, 8) and S.factorization(12) == (3, 4) and S.factorization(7) == (1, 7)
+    assert S.montage(np.zeros((6, 2, 2))).shape == (3 * 2, 2 * 2, 1)
+    img = np.linspace(0, 1, 4 * 6 * 3).reshape(4, 6, 3)
+    b = S.png_bytes(img)
+    assert b[:8] == b'\x89PNG\r\n\x1a\n'
+    pos, idat, hdr = 8, b'', None
+    while pos < len(b):
+        ln, tag = struct.unpack('>I', b[pos:pos + 4])[0], b[pos + 4:pos + 8]
+        data = b[pos + 8:pos + 8 + ln]
+        assert struct.unpack('>I', b[pos + 8 + ln:pos + 12 + ln])[0] == zlib.crc32(tag + data) & 0xffffffff
+        if tag == b'IHDR':
+            hdr = struct.unpack('>IIBBBBB', data)
+        if tag == b'IDAT':
+            idat += data
+        pos += 12 + ln
+    assert hdr == (6, 4, 8, 2, 0, 0, 0)
+    raw = zlib.decompress(idat)
+    rows = [raw[r * (1 + 18):(r + 1) * (1 + 18)] for r in range(4)]
+    assert all(r[0] == 0 for r in rows)
+    dec = np.frombuffer(b''.join(r[1:] for r in rows), dtype=np.uint8).reshape(4, 6, 3)
+    assert np.array_equal(dec, np.rint(img * 255).astype(np.uint8))
+    files = S.write_epoch(str(tmp_path), 1, {'g_loss': 1.5, 'd_loss': -0.25}, np.zeros((64, 8, 8, 3)), np.ones((64, 8, 8, 3)))
+    assert len(files) == 3 and open(files[0]).read().splitlines() == ['epoch,d_loss,g_loss', '1,-0.25,1.5']

@@ -148,6 +148,7 @@ def main(argv=None):
     util = importlib.import_module('3dgan_amd.util')
     datasets = importlib.import_module('3dgan_amd.datasets')
     ckpt = importlib.import_module('3dgan_amd.checkpoint')
+    summaries = importlib.import_module('3dgan_amd.summaries')
 
     if args.seed is None:
         args.seed = int.from_bytes(os.urandom(4), 'little')          # train.py:193-194 (kept an int, App. C-12)
@@ -215,6 +216,9 @@ def main(argv=None):
                 pbar.set_postfix(util.format_for_terminal(dict(status), prev_status))
         sess.global_epoch += 1                                                                         # train.py:322
         if chief:
+            real, fake = replica.samples(args.examples) if hasattr(replica, 'samples') else (None, None)
+            summaries.write_epoch(os.path.join(args.dir, 'summaries'), sess.global_epoch, status or {}, real, fake,
+                                  args.examples)                                                       # models/gan.py:93-107
             ckpt.save(os.path.join(args.dir, 'checkpoint-{}.npz'.format(sess.global_epoch)), replica, sess)   # :329
     if chief:
         message('\nTraining complete! Elapsed time: {}s'.format(int(time.time() - start_time)))
