@@ -883,6 +883,38 @@ extern "C" int tdg_vae_bce(int dtype, const float* x, const void* d, int rows, i
   return TDG_OK;
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) l1_loss_kernel(const float* __restrict__ x, const T* __restrict__ d, size_t n, int c, int cs,
+                                                     float scale, float shift, float inv_n, T* __restrict__ seed,
+                                                     float* __restrict__ partial) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c;
+    const int ch = (int)(i - r * c);
+    const size_t j = r * cs + ch;
+    const float u = scale * (x[i] + shift) - to_f32<T>(d[j]);           // x - d on the rescaled input
+    s += fabsf(u);
+    seed[j] = from_f32<T>(u > 0.f ? -inv_n : (u < 0.f ? inv_n : 0.f));   // AbsGrad: sign(u), sign(0) = 0; d u / d d = -1
+  }
+  s = block_sum256(s, sh);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" int tdg_l1_loss(int dtype, const float* x, const void* d, int rows, int c, int cs, float scale, float shift, void* seed,
+                           float* scal, void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(x && d && seed && scal && workspace && rows > 0 && c > 0 && cs >= c, "tdg_l1_loss: bad argument");
+  if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_l1_loss: workspace too small"); return TDG_EWORKSPACE; }
+  const float inv_n = 1.f / ((float)rows * (float)c);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(l1_loss_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, x, static_cast<const T*>(d),
+                       (size_t)rows * c, c, cs, scale, shift, inv_n, static_cast<T*>(seed), static_cast<float*>(workspace));
+  })
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
+                     RED_BLOCKS, scal, 0.f, inv_n);
+  TDG_HIP_LAUNCH_CHECK("l1_loss");
+  return TDG_OK;
+}
+
 __global__ void gp_scalars_kernel(const float* __restrict__ ss, float lambda, float* __restrict__ scal) {
   const float s = sqrtf(ss[0]);
   scal[0] = (s - 1.f) * (s - 1.f);

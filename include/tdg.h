@@ -213,6 +213,11 @@ int tdg_vae_kl(int dtype, const void* heads, int hs, int rows, int L, float* sca
  * seed = d decoder_loss / d d.  x: compact f32 [rows, c] in [0,1]; d, seed: [rows, cs] in dtype. */
 int tdg_vae_bce(int dtype, const float* x, const void* d, int rows, int c, int cs, void* seed, float* scal, void* workspace,
                 size_t workspace_bytes, void* stream);
+/* Convolutional autoencoder loss (models/cnn.py:31,75-79): with xs = scale * (x + shift) (the rescale to [-1,1]),
+ * scal[0] = mean |xs - d|, seed = d loss / d d = sign(d - xs) / (rows * c)  (sign(0) = 0, TF AbsGrad).
+ * x: compact f32 [rows, c]; d, seed: [rows, cs] in dtype. */
+int tdg_l1_loss(int dtype, const float* x, const void* d, int rows, int c, int cs, float scale, float shift, void* seed,
+                float* scal, void* workspace, size_t workspace_bytes, void* stream);
 /* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
  * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);

@@ -21,3 +21,17 @@ def test_vae_losses_and_gradients_match_autograd():
     for (k, v), gt in zip(Pt.items(), gs):
         gt = np.zeros(v.shape) if gt is None else gt.numpy()
         assert np.abs(g[k] - gt).max() <= 1e-8 * max(1.0, np.abs(gt).max()), k
+
+
+def test_cnn_oracle_loss_is_l1_of_rescaled_input():
+    """models/cnn.py:31,75-79: loss = mean |2(x-0.5) - d|, d in (-1,1) (tanh); one dense latent, no batch norm."""
+    from oracle import cnn_ref as CR
+    L, B = 8, 2
+    P = TR.to_torch(CR.init_params(L, 0, np.float64), torch.float64)
+    assert 'encoder/BatchNorm/beta' not in P and 'latent/vars/d2/weights' not in P
+    x = torch.tensor(np.random.default_rng(0).uniform(0, 1, (B, 64, 64, 3)))
+    loss, d = CR.forward(P, x)
+    assert d.shape == x.shape and float(d.abs().max()) < 1.0
+    assert np.allclose(float(loss), float((2 * (x - 0.5) - d).abs().mean()))
+    g = torch.autograd.grad(loss, list(P.values()))
+    assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in g)

@@ -78,7 +78,7 @@ def build_parser():
     add('--beta1', type=float, default=0.9)
     add('--beta2', type=float, default=0.999)
     add = model_args.add_argument
-    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan | vae | pix2pix.')
+    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan | vae | cnn | pix2pix.')
     add('--latent_size', type=int, default=200)
     add = data_args.add_argument
     add('--dataset', '--data', dest='dataset', type=lambda s: s.lower(), default='floorplans',
