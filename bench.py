@@ -136,7 +136,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):          # >= 2: first call runs eagerly, second captures the hipGraphs
+    for _ in range(2):                            # setup, not warm-up: the first call runs eagerly (lazy workspaces,
+        rep.train_func()                          # kernel attributes), the second captures the hipGraphs
+    for _ in range(args.warmup):                  # W untimed warm-up steps (graph replays)
         rep.train_func()
     sync()
     t0 = time.perf_counter()
