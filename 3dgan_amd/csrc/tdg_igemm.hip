@@ -412,10 +412,9 @@ struct DmaLoader {
     t_ok = (int)t < ntaps;
     const int pk = __builtin_amdgcn_ds_bpermute((int)(t_ok ? t : 0u) << 2, tapreg);   // lane i holds tap i: a lane crossbar
     dh = tap_dh(pk);                                                                  // read, not an LDS access the
-                                                                                      // compiler would fence the DMA for
-    dw = tap_dw(pk);
-    koff = (unsigned)((dh * SW + dw) * Cs + cv * VEC);
-    kbyte = (unsigned)step * IG_BKB;
+    dw = tap_dw(pk);                                                                  // compiler would fence the DMA for
+    koff = (unsigned)((dh * SW + dw) * Cs + cv * VEC);                                // (requesting the entry a step ahead
+    kbyte = (unsigned)step * IG_BKB;                                                  //  was measured: slower)
   }
   template <int P>
   __device__ __forceinline__ void piece(char* stage) const {
@@ -633,15 +632,27 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     }
     wait_barrier(nsteps > 1);
     int cur = 0, step = 0;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_issue = 0, s_mma = 0, s_sync = 0;
     for (; step < nsteps - 2; ++step) {
       const int nxt2 = cur == 0 ? 2 : cur - 1;         // (cur + 2) % 3
-      ld.prepare(step + 2);
+      TDG_STAMP(t0);
+      ld.prepare(step + 2);                            // (worked out among the MFMAs of the previous step instead, this
+      TDG_STAMP(t1);                                   //  block's 9 % of a step only moved into the MFMA phase: measured)
       const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
       const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
       dma_mma_step<T, TM, TN, true, ILV, LD>(acc, pA, pB, q, swl, ld, smem + nxt2 * STAGE);
+      TDG_STAMP(t2);
       wait_barrier(true);
+      TDG_STAMP(t3);
+      s_issue += t1 - t0; s_mma += t2 - t1; s_sync += t3 - t2;
       cur = cur == 2 ? 0 : cur + 1;
     }
+#ifdef TDG_STAMPS
+    if (args.stamps && lane == 0) {
+      unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o[0] = s_issue; o[1] = s_mma; o[2] = s_sync; o[3] = (unsigned long long)(nsteps > 2 ? nsteps - 2 : 0);
+    }
+#endif
     for (; step < nsteps; ++step) {
       const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
       const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;

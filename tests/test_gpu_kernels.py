@@ -277,3 +277,37 @@ def test_rng_statistics():
     z2 = torch.zeros(n, device=dev)
     L.call('tdg_random_normal', 0, 1234, 1, 0, n, K.ptr(z2), K.stream())
     assert torch.equal(z, z2)            # counter-based: same key/counter -> same stream
+
+
+def test_pack_filters_batch_equals_single_packs_and_timing_records():
+    """tdg_pack_filters == tdg_pack_filter_fwd + tdg_pack_filter_bwd per job (bit-identical packed bytes, including the
+    fused-class backward form of a thin big side); tdg_timing_* returns one record per conv GEMM kernel launch."""
+    K = pkg('kernels')
+    dev = torch.device('cuda:0')
+    convs, ws = [], []
+    for (n, h, w, cin, cout, k, s) in [(2, 16, 16, 200, 400, 5, 2), (2, 32, 32, 3, 200, 5, 2), (2, 8, 8, 40, 104, 5, 2)]:
+        big, small, conv = make_conv(K, 1, n, h, w, cin, cout, k, s, dev)
+        wt = torch.randn(k, k, cin, cout, device=dev) * 0.05
+        conv.pack(wt)
+        convs.append((conv, big, small, n))
+        ws.append(wt)
+    single = [(c.w_fwd.clone(), c.w_bwd.clone()) for c, _, _, _ in convs]
+    for c, _, _, _ in convs:
+        c.w_fwd.zero_()
+        c.w_bwd.zero_()
+    K.pack_all(K.make_pack_jobs([c.pack_job(wt) for (c, _, _, _), wt in zip(convs, ws)]))
+    torch.cuda.synchronize()
+    for (c, _, _, _), (f, b) in zip(convs, single):
+        assert torch.equal(c.w_fwd, f) and torch.equal(c.w_bwd, b)
+    K.timing_begin()
+    conv, big, small, n = convs[0]
+    conv.fwd(big.ptr(), small.ptr(), n)
+    conv.bwd_data(small.ptr(), big.ptr(), n)
+    dw = torch.zeros(5, 5, 200, 400, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n)
+    rec = K.timing_end()
+    names = [r[0] for r in rec]
+    assert len(rec) >= 4 and any('wgrad' in x for x in names) and 'slab_reduce' in names
+    gemm = [r for r in rec if r[2] > 0]
+    assert all(r[1] > 0 for r in rec) and abs(sum(r[2] for r in gemm) - 3 * conv.flops(n)) < 1e-6 * conv.flops(n)
+    assert K.timing_end() == []                  # nothing is recorded once timing is off
