@@ -24,6 +24,33 @@ from .ops import activations as A
 
 
 # ------------------------------------------------------------------------------ parameters
+class GraphRunner:
+    """Mixin: run a step body eagerly the first time (lazy workspaces, kernel attributes), capture it into a hipGraph
+    the second time and replay it afterwards.  Everything that varies per step must live at fixed device addresses
+    (batch staging buffer, Philox draw counter, Adam step count), so that a replay IS a new step.  Collectives and
+    host reads stay outside the captured bodies."""
+
+    def init_graphs(self, args, sess):
+        self.use_graphs = bool(getattr(args, 'use_graphs', True)) and sess.device.type == 'cuda' and not sess.check_numerics
+        self._warm, self._graphs = set(), {}
+
+    def _run(self, name, body):
+        if not self.use_graphs or self.sess.inject:
+            return body()
+        g = self._graphs.get(name)
+        if g is not None:
+            return g.replay()
+        if name not in self._warm:
+            self._warm.add(name)
+            return body()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            body()
+        self._graphs[name] = g
+        g.replay()
+
+
 class ParamStore:
     """Flat f32 parameter / gradient buckets of one net with named views
     (names as in the reference: `generator/vars/fc1/weights`, `generator/BatchNorm/beta`)."""

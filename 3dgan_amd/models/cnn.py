@@ -54,7 +54,7 @@ def decoder(x, latent_size, out_channels=3, reuse=False):
     return x
 
 
-class CnnReplica:
+class CnnReplica(engine.GraphRunner):
     def __init__(self, x_source, args, sess):
         self.args, self.sess, self.x_source = args, sess, x_source
         B, L = args.batch_size, args.latent_size
@@ -102,6 +102,7 @@ class CnnReplica:
         self.lat_conv = K.Conv(self.flat, self.Dn.x, 1, 1, 1, 0, 0)
         self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.init_graphs(args, sess)
         self.refresh()
 
     # ---- variables -----------------------------------------------------------------------------------
@@ -128,9 +129,20 @@ class CnnReplica:
 
     # ---- one training step (util.py:22-28 default_training) -------------------------------------------------
     def step(self, x01):
+        self.x_stage.copy_(x01.reshape(self.x_stage.shape))      # fixed address: the bodies below may be graph-captured
+        self._run('grads', self._grads)
+        self.sess.assert_finite(self.store, 'cnn_step')
+        self._scale = average_gradients(self.sess, self.store)   # RCCL, outside the graphs
+        self._run('apply', self._apply)
+        self.sess.global_step += 1
+
+    def _apply(self):
+        self.opt.step(self._scale)
+        self.refresh()
+
+    def _grads(self):
         B, L, dt = self.B, self.L, self.sess.dtype
         h, w, c = self.args.image_shape
-        self.x_stage.copy_(x01.reshape(self.x_stage.shape))
         _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), B * h * w, c, self.E.x.cs, 2.0, -0.5, self.E.x.ptr(0),
                   K.stream())                                                                    # models/cnn.py:31
         self.E.forward(0, B)
@@ -146,11 +158,6 @@ class CnnReplica:
         self.lat_conv.bwd_filter(self.flat.ptr(), self.Dn.dx.ptr(), g(self.wname).view(1, 1, 512, L), B, 0.0)
         self.lat_conv.bwd_data(self.Dn.dx.ptr(), self.dflat.ptr(), B)     # dL/d(c6 output); E.backward applies lrelu'
         self.E.backward(0, B, want_params=True)
-        self.sess.assert_finite(self.store, 'cnn_step')
-        scale = average_gradients(self.sess, self.store)
-        self.opt.step(scale)
-        self.sess.global_step += 1
-        self.refresh()
 
     def losses(self):
         s = self.scal.cpu().tolist()

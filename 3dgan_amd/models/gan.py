@@ -67,7 +67,7 @@ def discriminator(x, args, reuse=False):
 
 
 # ------------------------------------------------------------------------------ one replica
-class GanReplica:
+class GanReplica(engine.GraphRunner):
     """The per-GPU replica ("tower") of models/gan.py:55-70 plus its optimizers (:46,79-81)."""
 
     # device scalar slots
@@ -117,10 +117,8 @@ class GanReplica:
         self.g_opt, self.d_opt = init_optimizer(args, self.g_store), init_optimizer(args, self.d_store)   # :46
         self.img_elems = self.D.x.image_elems        # channel-padded image size in HBM
         # hipGraph replay of the two step bodies (launch-bound otherwise: ~600 small launches per iteration)
-        self.use_graphs = bool(getattr(args, 'use_graphs', True)) and dev.type == 'cuda' and not sess.check_numerics
+        self.init_graphs(args, sess)
         self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
-        self._graphs = {}
-        self._warm = set()
         self._seed_g = None
         self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float32, device=dev)
@@ -166,25 +164,6 @@ class GanReplica:
         h, w, c = self.args.image_shape
         _lib.call('tdg_affine_cast_rows', self.sess.dtype, K.ptr(self.x_stage), self.B * h * w, c, self.D.x.cs, 2.0, -0.5,
                   self.D.x.ptr(0), K.stream())
-
-    def _run(self, name, body):
-        """Run a step body eagerly the first time (lazy workspaces, kernel attributes), capture it into a
-        hipGraph the second time and replay it afterwards.  All step-varying inputs (batch, RNG draw
-        counter, Adam step count) live at fixed device addresses, so a replay is a new step."""
-        if not self.use_graphs or self.sess.inject:
-            return body()
-        g = self._graphs.get(name)
-        if g is not None:
-            return g.replay()
-        if name not in self._warm:
-            self._warm.add(name)
-            return body()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            body()
-        self._graphs[name] = g
-        g.replay()
 
     def _generate(self):
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246

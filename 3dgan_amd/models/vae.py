@@ -63,7 +63,7 @@ def decoder(x, latent_size, out_channels=3, reuse=False):
     return x
 
 
-class VaeReplica:
+class VaeReplica(engine.GraphRunner):
     S_DLOSS, S_LLOSS = 0, 1
 
     def __init__(self, x_source, args, sess):
@@ -120,6 +120,7 @@ class VaeReplica:
         self.eps = K.Act(B, 1, 1, L, dt, dev)
         self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.init_graphs(args, sess)
         self.refresh()
 
     # ---- variables -----------------------------------------------------------------------------------
@@ -151,9 +152,20 @@ class VaeReplica:
 
     # ---- one training step (util.py:22-28 default_training) -------------------------------------------------
     def step(self, x01):
+        self.x_stage.copy_(x01.reshape(self.x_stage.shape))      # fixed address: the bodies below may be graph-captured
+        self._run('grads', self._grads)
+        self.sess.assert_finite(self.store, 'vae_step')
+        self._scale = average_gradients(self.sess, self.store)   # RCCL, outside the graphs
+        self._run('apply', self._apply)
+        self.sess.global_step += 1
+
+    def _apply(self):
+        self.opt.step(self._scale)
+        self.refresh()
+
+    def _grads(self):
         B, L, dt = self.B, self.L, self.sess.dtype
         h, w, c = self.args.image_shape
-        self.x_stage.copy_(x01.reshape(self.x_stage.shape))
         _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), B * h * w, c, self.E.x.cs, 1.0, 0.0, self.E.x.ptr(0), K.stream())
         self.E.forward(0, B)
         self.head_conv.fwd(self.flat.ptr(), self.heads.ptr(), B, K.epilogue(bias=self.b_heads))
@@ -180,11 +192,6 @@ class VaeReplica:
         g('latent/vars/d1/bias').copy_(self.db_heads[:L])
         g('latent/vars/d2/bias').copy_(self.db_heads[L:])
         self.E.backward(0, B, want_params=True)
-        self.sess.assert_finite(self.store, 'vae_step')
-        scale = average_gradients(self.sess, self.store)
-        self.opt.step(scale)
-        self.sess.global_step += 1
-        self.refresh()
 
     def losses(self):
         s = self.scal.cpu().tolist()
