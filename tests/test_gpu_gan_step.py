@@ -197,3 +197,75 @@ def test_vanilla_gan_step_f32():
             continue
         assert relerr(new[k], tr.P[k]) < 1e-3, k
     assert sess.global_step == 2
+
+
+def _free_run(model, optimizer, lr, beta1, beta2, shape, iters, B=16, L=40):
+    """HIP f32 replica, float64 oracle and float32 oracle stepped side by side on the same batches / z / alpha.
+    Returns [(iteration, loss name, |hip - f64|, |torch f32 - f64|)] relative to max(1, |loss|), and the last loss dict."""
+    from oracle import torch_ref as TR
+    gan, rt = pkg('models.gan'), pkg('runtime')
+    dev = torch.device('cuda:0')
+    args = SimpleNamespace(model=model, batch_size=B, latent_size=L, image_shape=shape, n_gpus=1, optimizer=optimizer,
+                           lr=lr, beta1=beta1, beta2=beta2, decay=0.9, momentum=0.01, centered=False, n_disc_train=5,
+                           display_d_loss=True)
+    cfg = G.make_cfg(model, shape, L, B)
+    P = G.init_params(cfg, 3, np.float64)
+    rng = np.random.default_rng(11)
+    n = args.n_disc_train + 1
+    batches = [rng.uniform(0, 1, (B,) + shape).astype(np.float32) for _ in range(iters * n)]
+    zs = [rng.standard_normal((B, L)).astype(np.float32) for _ in range(iters * n)]
+    als = [rng.uniform(0, 1, (B, 1)).astype(np.float32) for _ in range(iters * n)]
+    sess = rt.Session(device=dev, dtype=0, seed=0, rank=0, world_size=1)
+    rep = gan.GanReplica(ListSource(batches, dev), args, sess)
+    rep.load_variables({k: v.astype(np.float32) for k, v in P.items()})
+    tr64 = TR.TorchGanTrainer(TR.to_torch(P, torch.float64), cfg, args)
+    tr32 = TR.TorchGanTrainer(TR.to_torch(P, torch.float32), cfg, args)
+    hist = []
+    for it in range(iters):
+        sl = slice(it * n, (it + 1) * n)
+        sess.inject = {'z': list(zs[sl])}
+        if model == 'iwgan':
+            sess.inject['alpha'] = list(als[sl])
+        out = rep.train_func()
+        ref = tr64.train_func([torch.tensor(b, dtype=torch.float64) for b in batches[sl]],
+                              [torch.tensor(z, dtype=torch.float64) for z in zs[sl]],
+                              [torch.tensor(a, dtype=torch.float64) for a in als[sl]])
+        r32 = tr32.train_func([torch.tensor(b) for b in batches[sl]], [torch.tensor(z) for z in zs[sl]],
+                              [torch.tensor(a) for a in als[sl]])
+        for k in ('g_loss', 'd_loss'):
+            scale = max(1.0, abs(ref[k]))
+            assert np.isfinite(out[k]), (it, k, out[k])
+            hist.append((it, k, abs(out[k] - ref[k]) / scale, abs(r32[k] - ref[k]) / scale))
+    assert sess.global_step == iters * n
+    return hist, out
+
+
+def _check_free_run(hist, exact_iters):
+    """|hip - f64| < 1e-3 outright for the first `exact_iters` iterations; afterwards within max(1e-3, 5 x the largest
+    |torch f32 - f64| seen so far): float32 rounding is amplified from step to step in ANY float32 implementation, the
+    oracle's own float32 run is the yardstick for how far a float32 trajectory may be from the float64 one."""
+    worst_sens = 0.0
+    for it, k, err, sens in hist:
+        worst_sens = max(worst_sens, sens)
+        assert err < (1e-3 if it < exact_iters else max(1e-3, 5.0 * worst_sens)), (it, k, err, sens, worst_sens)
+
+
+def test_iwgan_20_iterations_track_the_oracle():
+    """The headline schedule (iwgan, adam 1e-4 / 0.5 / 0.9, n_disc_train 5) free-running for 20 train_func calls = 120
+    optimizer steps on fresh batches with injected z and alpha (widths reduced to L=40, batch 16, so the oracle finishes
+    in seconds).  Measured: |HIP f32 - oracle f64| 1e-8 .. 4e-4 over the first 7 iterations, then both float32 runs
+    (HIP and the oracle's own) drift from float64 together, 1e-3 .. 2e-2 by iteration 18."""
+    hist, out = _free_run('iwgan', 'adam', 1e-4, 0.5, 0.9, (32, 32, 3), 20)
+    print('iteration, loss, |hip-f64|, |torch f32-f64| (relative): ' + '; '.join('%d %s %.1e %.1e' % h for h in hist[::6]))
+    assert set(out) == {'g_loss', 'd_loss'}
+    _check_free_run(hist, 6)
+
+
+def test_wgan_mnist_like_free_run():
+    """SURVEY section 8d config 1 (`--model wgan --dataset mnist` padded to 32x32x1, rmsprop defaults).  The reference's
+    wgan never clips (App. C-3): the critic runs away (|loss| past 50 within a few iterations), so float32 trajectories
+    leave the float64 one early -- the oracle's own float32 run by 4e-3 at the third iteration."""
+    hist, out = _free_run('wgan', 'rmsprop', 1e-3, 0.9, 0.999, (32, 32, 1), 8)
+    print('iteration, loss, |hip-f64|, |torch f32-f64| (relative): ' + '; '.join('%d %s %.1e %.1e' % h for h in hist))
+    assert set(out) == {'g_loss', 'd_loss'}
+    _check_free_run(hist, 2)
