@@ -404,10 +404,39 @@ class SeqNet:
         return self.dx
 
     # -- gradient-penalty tangent pass (models/gan.py:228 second order; oracle/gan_ref.py) -------
+    def tangent_forward(self, img0, n, acc=True):
+        """With u in `self.tan_in` (n images): the tangents t_i = act'(h_i) * conv_i(t_{i-1}) (no bias) of every conv
+        layer, and d(fc2 weights) += sum_rows t_last.  Only BN-free (l)relu critics (the iwgan D)."""
+        beta = 1.0 if acc else 0.0
+        g = self.store.grad
+        t_prev = self.tan_in
+        for L in self.layers:
+            r0, rn = img0 * L.rpi, n * L.rpi
+            if L.rowdot:
+                cols = L.spec.in_size
+                K.colsum_weighted(self.ws, self.dtype, t_prev.ptr(0), rn, cols, cols, None, g(L.wname), beta)
+                break
+            if L.spec.use_bn or L.spec.kind == 'deconv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
+                raise NotImplementedError('tangent pass: layer %s is not a BN-free (l)relu conv' % L.spec.name)
+            L.tan_src = _alias_rows(t_prev, L.rpi, *L.spec.in_shape) if t_prev is not self.tan_in else self.tan_in
+            mmode = K.MASK_LRELU if L.act.code == K.ACT_LRELU else K.MASK_RELU
+            L.conv.fwd(L.tan_src.ptr(0), L.tan.ptr(0), rn, K.epilogue(mask_mode=mmode, leak=L.act.leak, mask_src=L.h.ptr(r0)))
+            t_prev = L.tan
+
+    def tangent_wgrad(self, img0, n, layers, acc=True):
+        """dW_i += bwd_filter(t_{i-1}, delta_i) for the given conv layers (after tangent_forward, with the first-order
+        deltas of images [img0, img0+n) in place).  The layers are independent of each other: the caller picks the
+        order (the largest filter first, so that its all-reduce can start while the others are still being computed)."""
+        beta = 1.0 if acc else 0.0
+        for L in layers:
+            L.conv.bwd_filter(L.tan_src.ptr(0), L.delta.ptr(img0 * L.rpi), self.store.grad(L.wname), n * L.rpi, beta)
+
+    def conv_layers(self):
+        return [L for L in self.layers if not L.rowdot]
+
     def tangent_backward(self, img0, n, acc=True):
-        """With u in `self.tan_in` (n images) and the first-order deltas of images [img0, img0+n)
-        in place: t_i = act'(h_i) * conv_i(t_{i-1}) (no bias), dW_i += bwd_filter(t_{i-1}, delta_i),
-        d(fc2 weights) += sum_rows t_last.  Only BN-free (l)relu critics (the iwgan D)."""
+        """The whole tangent pass, layer by layer: dW_i += bwd_filter(t_{i-1}, delta_i) right after t_{i-1} was produced
+        (it is still cache-resident then: measured 0.14 ms per D step faster than tangents first, filter gradients after)."""
         beta = 1.0 if acc else 0.0
         g = self.store.grad
         t_prev = self.tan_in

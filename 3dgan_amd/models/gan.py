@@ -118,6 +118,8 @@ class GanReplica(engine.GraphRunner):
         self.img_elems = self.D.x.image_elems        # channel-padded image size in HBM
         # hipGraph replay of the two step bodies (launch-bound otherwise: ~600 small launches per iteration)
         self.init_graphs(args, sess)
+        # the conv layer with the largest filter: its gradient slice is exchanged first (d_step)
+        self._d_big_layer = max(self.D.conv_layers(), key=lambda L: self.d_store[L.wname].numel())
         self.x_stage = torch.zeros(B, h, w, c, dtype=torch.float32, device=dev)
         self._seed_g = None
         self.alpha = torch.zeros(B, dtype=torch.float32, device=dev)
@@ -213,12 +215,32 @@ class GanReplica(engine.GraphRunner):
 
     # -- steps -------------------------------------------------------------------------------------
     def d_step(self, x01):
-        """One run of d_train_op (models/gan.py:152,171): d_loss gradients w.r.t. D, averaged, applied."""
+        """One run of d_train_op (models/gan.py:152,171): d_loss gradients w.r.t. D, averaged, applied.
+
+        Several replicas (iwgan): the critic's largest filter (c3: 80 % of its parameters) gets its last contribution
+        -- the tangent-pass filter gradient -- FIRST, and its slice of the flat bucket starts its RCCL all-reduce while
+        the remaining tangent-pass filter gradients are still being computed (second captured body); the small rest of
+        the bucket follows.  One replica: a single captured body, no exchange."""
         self._load_real(x01)
-        self._run('d_grads', self._d_grads)
-        self.sess.assert_finite(self.d_store, 'd_step')
-        scale = average_gradients(self.sess, self.d_store)            # models/gan.py:77 (RCCL, outside the graphs)
-        self._scale = scale
+        sess, store = self.sess, self.d_store
+        if sess.world_size > 1 and self.iwgan:
+            big = self._d_big_layer
+            off, shape = store.index[big.wname]
+            lo, hi = off, store.index[big.bname][0] + (big.spec.out_size + 3) // 4 * 4    # [weights | bias] are adjacent
+            self._run('d_grads_a', self._d_grads_a)
+            work = sess.allreduce_async(store.grads[lo:hi])
+            self._run('d_grads_b', self._d_grads_b)
+            sess.assert_finite(store, 'd_step')
+            work.wait()
+            if lo > 0:
+                sess.allreduce_mean_scale(store.grads[:lo])
+            if hi < store.size:
+                sess.allreduce_mean_scale(store.grads[hi:])
+            self._scale = 1.0 / sess.world_size
+        else:
+            self._run('d_grads', self._d_grads)
+            sess.assert_finite(store, 'd_step')
+            self._scale = average_gradients(sess, store)              # models/gan.py:77 (RCCL, outside the graphs)
         self._run('d_apply', self._d_apply)
         self.sess.global_step += 1
 
@@ -231,6 +253,9 @@ class GanReplica(engine.GraphRunner):
         self.G.repack()
 
     def _d_grads(self):
+        self._d_grads_a(whole=True)
+
+    def _d_grads_a(self, whole=False):
         B, R = self.B, self.B * self.rows_per_image
         self._rescale_real()
         self._generate()
@@ -247,10 +272,19 @@ class GanReplica(engine.GraphRunner):
             # u = d(lambda * penalty)/dv = lambda * 2 (s-1)/s * v, then the tangent pass accumulates dW
             _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
                       K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
-            self.D.tangent_backward(2 * B, B, acc=True)
+            if whole:                                                 # one replica: layer by layer (cache-friendlier)
+                self.D.tangent_backward(2 * B, B, acc=True)
+            else:                                                     # several: the largest filter's gradient first
+                self.D.tangent_forward(2 * B, B, acc=True)
+                self.D.tangent_wgrad(2 * B, B, [self._d_big_layer], acc=True)
         else:
             self.D.backward(0, B, bn_pass=0, want_params=True, acc=False)
             self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
+
+    def _d_grads_b(self):
+        if self.iwgan:
+            rest = [L for L in reversed(self.D.conv_layers()) if L is not self._d_big_layer]
+            self.D.tangent_wgrad(2 * self.B, self.B, rest, acc=True)
 
     def g_step(self, x01):
         """One run of [g_train_op, losses] (models/gan.py:153,172)."""

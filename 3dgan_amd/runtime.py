@@ -82,6 +82,14 @@ class Session:
             return 1.0 / self.world_size
         return 1.0
 
+    def allreduce_async(self, flat_slice):
+        """Start summing a slice of a flat gradient bucket over replicas (RCCL runs on its own stream, after the work
+        already enqueued on the current stream); returns a handle whose wait() orders the current stream behind it, or
+        None on a single replica."""
+        if self.world_size > 1:
+            return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
     def assert_finite(self, store, what):
         """--check_numerics (hem/util/training.py:52-53): name the offending variable."""
         if not self.check_numerics:
