@@ -31,7 +31,7 @@ def test_cnn_oracle_loss_is_l1_of_rescaled_input():
     assert 'encoder/BatchNorm/beta' not in P and 'latent/vars/d2/weights' not in P
     x = torch.tensor(np.random.default_rng(0).uniform(0, 1, (B, 64, 64, 3)))
     loss, d = CR.forward(P, x)
-    assert d.shape == x.shape and float(d.abs().max()) < 1.0
-    assert np.allclose(float(loss), float((2 * (x - 0.5) - d).abs().mean()))
+    assert d.shape == x.shape and float(d.detach().abs().max()) < 1.0
+    assert np.allclose(float(loss.detach()), float((2 * (x - 0.5) - d.detach()).abs().mean()))
     g = torch.autograd.grad(loss, list(P.values()))
     assert all(torch.isfinite(t).all() and t.abs().sum() > 0 for t in g)
