@@ -57,6 +57,7 @@ SIGNATURES = {
     'tdg_conv2d_bwd_data': (_i, [_PD, _i, _vp, _vp, _vp, _PE, _vp]),
     'tdg_conv2d_bwd_filter_workspace_bytes': (_sz, [_PD, _i]),
     'tdg_conv2d_bwd_filter': (_i, [_PD, _i, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    'tdg_conv2d_bwd_filter2': (_i, [_PD, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_rowdot': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'tdg_rowouter': (_i, [_i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     'tdg_colsum_weighted': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _sz, _vp]),

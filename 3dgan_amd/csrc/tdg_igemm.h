@@ -47,9 +47,11 @@ struct IgArgs {
 // Filter-gradient GEMM  out[(t,c)][n] = sum_m gather(A)[m][(t,c)] * G[m][n], split over m.
 struct WgArgs {
   const void* src;       // gathered operand (big-side tensor)
+  const void* src2;      // second gathered tensor: rows m >= m_switch are image (m / GHW - img_switch) of it (or null)
   const void* g;         // dense rows [M][Gs] (small-side tensor)
   float* slabs;          // [nsplit][ntaps*Clog][N] f32 partials
-  unsigned src_bytes, g_bytes;
+  unsigned src_bytes, src2_bytes, g_bytes;
+  int m_switch, img_switch;   // (m_switch = M and src2 = null: one source)
   int M, GH, GW, SH, SW, sigma;
   int C, Clog, Cs, ntaps;  // effective / logical channels per tap, channel stride
   int KK;                  // ntaps * C

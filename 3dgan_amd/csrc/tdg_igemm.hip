@@ -1047,8 +1047,9 @@ __device__ __forceinline__ int wd_f(int row) { return (row & 3) | (((row >> 3) &
 // one piece behind each of the first 8 MFMA groups of a step (see DmaLoader).
 struct WdLoader {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  i32x4 rA, rG;
+  i32x4 rA, rA2, rG;
   unsigned lds0;                    // LDS byte address of the ring
+  int m_switch, img_switch;         // rows >= m_switch gather from the second tensor (its image 0 = image img_switch)
   FastDiv fd_ghw, fd_gw;
   int GHW, GW, SH, SW, Cs, sigma, Gs, m_end;
   int a_dh, a_dw, a_koff, a_kok, g_n, g_nok, hrow;
@@ -1062,15 +1063,17 @@ struct WdLoader {
     const int okm = m < m_end;
     if constexpr ((P & 1) == 0) {
       const unsigned mm = okm ? (unsigned)m : 0u;
-      const unsigned nb = fd_div(mm, fd_ghw);
-      const unsigned rem = mm - nb * (unsigned)GHW;
+      const bool second = mstep + 2 * I >= m_switch;          // wave-uniform (m_switch is even: both rows on one side)
+      const unsigned nbg = fd_div(mm, fd_ghw);
+      const unsigned rem = mm - nbg * (unsigned)GHW;
+      const unsigned nb = second ? nbg - (unsigned)img_switch : nbg;
       const unsigned a = fd_div(rem, fd_gw);
       const unsigned b = rem - a * (unsigned)GW;
       const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
       const int ok = okm & a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
       const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
       const unsigned offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
-      lds_dma_b128(rA, offa, lds0 + (unsigned)(stage_off + I * 1024));
+      lds_dma_b128(second ? rA2 : rA, offa, lds0 + (unsigned)(stage_off + I * 1024));
     } else {
       const unsigned offg = (okm & g_nok) ? ((unsigned)m * (unsigned)Gs + (unsigned)g_n) * 2u : OOB_OFFSET;
       lds_dma_b128(rG, offg, lds0 + (unsigned)(stage_off + SLABB + I * 1024));
@@ -1160,6 +1163,8 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
 
   WdLoader ld;
   ld.rA = rA; ld.rG = rG;
+  ld.rA2 = make_rsrc_words(args.src2 ? args.src2 : args.src, args.src2 ? args.src2_bytes : args.src_bytes);
+  ld.m_switch = args.m_switch; ld.img_switch = args.img_switch;
   ld.lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
   ld.fd_ghw = args.fd_ghw; ld.fd_gw = args.fd_gw;
   ld.GHW = GHW; ld.GW = GW; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.Gs = Gs; ld.m_end = m_end;
@@ -2176,8 +2181,28 @@ size_t tdg_conv2d_bwd_filter_workspace_bytes(const TdgConvDesc* d, int n_images)
   return (size_t)ns * (size_t)tdg_round_up((long long)d->kh * d->kw * d->c * d->k, 4) * sizeof(float);
 }
 
+static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, int n_first, const void* x2, const void* y,
+                           float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
+
 int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, const void* y, float* dw,
                           float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  return bwd_filter_impl(d, n_images, x, n_images, nullptr, y, dw, beta, workspace, workspace_bytes, stream);
+}
+
+int tdg_conv2d_bwd_filter2(const TdgConvDesc* d, int n_images, const void* x, int n_first, const void* x2, const void* y,
+                           float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(n_first > 0 && n_first < n_images && x2, "tdg_conv2d_bwd_filter2: n_first %d outside (0, %d) or null x2", n_first, n_images);
+  // one launch when the LDS-DMA kernel applies and the switch row is even (a 2-row DMA instruction never straddles it)
+  if (wgrad_use_dma(d) && ((long long)n_first * d->oh * d->ow) % 2 == 0)
+    return bwd_filter_impl(d, n_images, x, n_first, x2, y, dw, beta, workspace, workspace_bytes, stream);
+  int rc = bwd_filter_impl(d, n_first, x, n_first, nullptr, y, dw, beta, workspace, workspace_bytes, stream);
+  if (rc) return rc;
+  const char* y2 = static_cast<const char*>(y) + (size_t)n_first * d->oh * d->ow * d->ks * tdg_dtype_size(d->dtype);
+  return bwd_filter_impl(d, n_images - n_first, x2, n_images - n_first, nullptr, y2, dw, 1.0f, workspace, workspace_bytes, stream);
+}
+
+static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, int n_first, const void* x2, const void* y,
+                           float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream) {
   int rc = validate_desc(d, "tdg_conv2d_bwd_filter");
   if (rc) return rc;
   TDG_CHECK_ARG(n_images > 0 && n_images <= d->n, "tdg_conv2d_bwd_filter: n_images %d outside (0, %d]", n_images, d->n);
@@ -2199,9 +2224,14 @@ int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, con
   a.src = x;
   a.g = y;
   a.slabs = static_cast<float*>(workspace);
-  a.src_bytes = (unsigned)((long long)n_images * d->h * d->w * d->cs * es);
+  a.src_bytes = (unsigned)((long long)n_first * d->h * d->w * d->cs * es);
+  a.src2 = x2;
+  a.src2_bytes = (unsigned)((long long)(n_images - n_first) * d->h * d->w * d->cs * es);
   a.g_bytes = (unsigned)((long long)n_images * d->oh * d->ow * d->ks * es);
   a.M = n_images * d->oh * d->ow;
+  a.m_switch = n_first * d->oh * d->ow;
+  a.img_switch = n_first;
+  TDG_CHECK_ARG(!x2 || ((uintptr_t)x2 & 15) == 0, "tdg_conv2d_bwd_filter2: x2 must be 16-byte aligned");
   a.GH = d->oh; a.GW = d->ow; a.SH = d->h; a.SW = d->w; a.sigma = d->stride;
   a.C = C; a.Clog = d->c; a.Cs = d->cs; a.ntaps = d->kh * d->kw;
   a.KK = a.ntaps * C;

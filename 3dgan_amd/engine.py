@@ -341,10 +341,11 @@ class SeqNet:
 
     # -- backward ----------------------------------------------------------------------------------
     def backward(self, img0, n, bn_pass=0, want_params=True, want_dx=False, acc=False, param_images=None,
-                 dx_images=None):
+                 dx_images=None, defer_wgrad=False):
         """Backprop from the last layer's seed (rowdot: L.seed; else L.gout) on images
         [img0, img0+n).  Parameter gradients cover `param_images` = (first, count) (default: the same
-        range) and are accumulated into the store when `acc`.  Returns dL/d(net input) if asked."""
+        range) and are accumulated into the store when `acc`.  With `defer_wgrad` the conv filter gradients are left
+        to a later merged_wgrad() (bias gradients are still taken here).  Returns dL/d(net input) if asked."""
         beta = 1.0 if acc else 0.0
         p0, pn = (img0, n) if param_images is None else param_images
         g = self.store.grad
@@ -391,7 +392,9 @@ class SeqNet:
                           L.act.leak, L.delta.ptr(r0), K.stream())
             if want_params and qn > 0:
                 K.bias_grad(self.ws, L.delta, L.spec.out_size, g(L.bname), rows=qn * hw, beta=beta, dy_ptr=L.delta.ptr(q0))
-                if L.spec.kind == 'deconv2d':
+                if defer_wgrad:
+                    pass
+                elif L.spec.kind == 'deconv2d':
                     L.conv.bwd_filter(L.delta.ptr(q0), L.inp.ptr(q0), g(L.wname), qn, beta)
                 else:
                     L.conv.bwd_filter(L.inp.ptr(q0), L.delta.ptr(q0), g(L.wname), qn, beta)
@@ -433,6 +436,16 @@ class SeqNet:
 
     def conv_layers(self):
         return [L for L in self.layers if not L.rowdot]
+
+    def merged_wgrad(self, n_first, n_tan, layers, acc=False):
+        """dW_i (+)= bwd_filter over images [0, n_first) of the layer input (first-order rows) AND the n_tan tangent rows
+        t_{i-1} against delta_i of images [0, n_first + n_tan) -- ONE GEMM per layer (tdg_conv2d_bwd_filter2) where the
+        first-order and the tangent-pass filter gradients used to be two plus two slab reductions.  Needs the deltas of
+        backward(0, n_first + n_tan, ..., defer_wgrad=True) and tangent_forward(n_first, n_tan) in place."""
+        beta = 1.0 if acc else 0.0
+        for L in layers:
+            L.conv.bwd_filter2(L.inp.ptr(0), n_first * L.rpi, L.tan_src.ptr(0), L.delta.ptr(0), self.store.grad(L.wname),
+                               (n_first + n_tan) * L.rpi, beta)
 
     def tangent_backward(self, img0, n, acc=True):
         """The whole tangent pass, layer by layer: dW_i += bwd_filter(t_{i-1}, delta_i) right after t_{i-1} was produced

@@ -212,6 +212,16 @@ class Conv:
         TIMER.wrap(self._tag('bwd_filter'), self.flops(n_images), go) if TIMER is not None else go()
 
 
+    def bwd_filter2(self, x_ptr, n_first, x2_ptr, y_ptr, dw, n_images, beta=0.0):
+        """Filter gradient over n_images whose big-side rows come from two tensors (tdg_conv2d_bwd_filter2)."""
+        ws = self.workspace()
+
+        def go():
+            _lib.call('tdg_conv2d_bwd_filter2', C.byref(self.desc), n_images, x_ptr, n_first, x2_ptr, y_ptr, ptr(dw), beta,
+                      ptr(ws), ws.numel(), stream())
+        TIMER.wrap(self._tag('bwd_filter'), self.flops(n_images), go) if TIMER is not None else go()
+
+
 class Workspace:
     """Scratch for the two-stage reductions (BN, bias grads, sumsq)."""
 

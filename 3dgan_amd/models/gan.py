@@ -267,16 +267,17 @@ class GanReplica(engine.GraphRunner):
         self._seed(1, 1.0 / R)                                        # d/d(d_fake) of  mean(d_fake)
         if self.iwgan:
             self._seed(2, 1.0)                                        # tf.gradients(d_interpolates, ...) (:228)
-            self.D.backward(0, 3 * B, want_params=True, want_dx=True, param_images=(0, 2 * B), dx_images=(2 * B, B))
+            # first-order backward with the conv filter gradients deferred: they are taken together with the tangent-pass
+            # ones, one GEMM per layer over [D(x) rows | D(g) rows | tangent rows] (engine.SeqNet.merged_wgrad)
+            self.D.backward(0, 3 * B, want_params=True, want_dx=True, param_images=(0, 2 * B), dx_images=(2 * B, B),
+                            defer_wgrad=True)
             self._penalty_from_v()
-            # u = d(lambda * penalty)/dv = lambda * 2 (s-1)/s * v, then the tangent pass accumulates dW
+            # u = d(lambda * penalty)/dv = lambda * 2 (s-1)/s * v, then the tangent pass
             _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
                       K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
-            if whole:                                                 # one replica: layer by layer (cache-friendlier)
-                self.D.tangent_backward(2 * B, B, acc=True)
-            else:                                                     # several: the largest filter's gradient first
-                self.D.tangent_forward(2 * B, B, acc=True)
-                self.D.tangent_wgrad(2 * B, B, [self._d_big_layer], acc=True)
+            self.D.tangent_forward(2 * B, B, acc=True)
+            convs = list(reversed(self.D.conv_layers())) if whole else [self._d_big_layer]   # several replicas: the
+            self.D.merged_wgrad(2 * B, B, convs)                      # largest filter first, the rest in _d_grads_b
         else:
             self.D.backward(0, B, bn_pass=0, want_params=True, acc=False)
             self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
@@ -284,7 +285,7 @@ class GanReplica(engine.GraphRunner):
     def _d_grads_b(self):
         if self.iwgan:
             rest = [L for L in reversed(self.D.conv_layers()) if L is not self._d_big_layer]
-            self.D.tangent_wgrad(2 * self.B, self.B, rest, acc=True)
+            self.D.merged_wgrad(2 * self.B, self.B, rest)
 
     def g_step(self, x01):
         """One run of [g_train_op, losses] (models/gan.py:153,172)."""

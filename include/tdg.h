@@ -130,6 +130,12 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
 size_t tdg_conv2d_bwd_filter_workspace_bytes(const TdgConvDesc* d, int n_images);
 int tdg_conv2d_bwd_filter(const TdgConvDesc* d, int n_images, const void* x, const void* y,
                           float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
+/* The same sum with the big-side rows coming from TWO tensors: images [0, n_first) from x, images [n_first, n_images)
+ * from x2 (its image 0 first); y holds all n_images.  One launch instead of two plus one slab reduction less: the
+ * critic's filter gradient of the iwgan D step = first-order rows (layer inputs of D(x), D(g)) + tangent-pass rows
+ * (tangents of the penalty's double backward, models/gan.py:228) against one delta tensor. */
+int tdg_conv2d_bwd_filter2(const TdgConvDesc* d, int n_images, const void* x, int n_first, const void* x2, const void* y,
+                           float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- dense fc2-style row ops (tf.matmul with one output unit, ops/layers.py:57 via
  *      models/gan.py:285, and its autodiff) --------------------------------------------- */

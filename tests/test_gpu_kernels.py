@@ -311,3 +311,28 @@ def test_pack_filters_batch_equals_single_packs_and_timing_records():
     gemm = [r for r in rec if r[2] > 0]
     assert all(r[1] > 0 for r in rec) and abs(sum(r[2] for r in gemm) - 3 * conv.flops(n)) < 1e-6 * conv.flops(n)
     assert K.timing_end() == []                  # nothing is recorded once timing is off
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', [(6, 16, 16, 200, 400, 5, 2, 4), (5, 8, 8, 40, 104, 5, 2, 2), (4, 32, 32, 3, 200, 5, 2, 3)])
+def test_bwd_filter_two_sources(case, dtype):
+    """tdg_conv2d_bwd_filter2 (rows of the first n_first images from one tensor, the rest from another) against the
+    oracle's conv2d_backprop_filter on the concatenated input, with accumulation into an existing dw."""
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s, n_first = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev)
+    dy = rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32)
+    dw0 = rng.standard_normal((k, k, cin, cout)).astype(np.float32)
+    if dtype == 1:
+        x, dy = bf16_round(x), bf16_round(dy)
+    first, second = big.like().set(x), big.like()
+    second.set(np.concatenate([x[n_first:], np.zeros_like(x[:n_first])]))      # its image 0 is image n_first
+    first.set(np.concatenate([x[:n_first], 9.0 * np.ones_like(x[n_first:])]))  # rows past n_first must not be read
+    small.set(dy)
+    dw = torch.tensor(dw0, device=dev)
+    conv.bwd_filter2(first.ptr(), n_first, second.ptr(), small.ptr(), dw, n, beta=0.5)
+    ref = 0.5 * dw0 + T.conv2d_backprop_filter(x.astype(np.float64), (k, k, cin, cout), dy.astype(np.float64), s)
+    assert relerr(dw.cpu().numpy(), ref) < TOL[dtype]
