@@ -1598,6 +1598,8 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     if (dma_mode == 3) bm = 192;
     if (dma_mode == 4) bm = 256;
     static const int ring192 = getenv("TDG_RING") ? atoi(getenv("TDG_RING")) : 3;     // diagnostics: 2 = 2-stage ring on the 192-row tile
+    // (a 64-row tile, two workgroups per CU, was tried for the 4-step c1 forward: no change -- with K padded 75 -> 256
+    //  and N 200 -> 224 that GEMM is bound by its padded MFMA work, not by serialised prologue / epilogue phases)
     if (bm == 128) return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
     if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
     return launch_fwd_dma<T, 256, 208, 2>(a, mmax, s);
@@ -2137,7 +2139,8 @@ static bool wgrad_use_dma(const TdgConvDesc* d) {
   if (e && atoi(e) == 0) return false;
   if (d->dtype != TDG_BF16) return false;
   const int ce = eff_channels(d->c, d->cs, 8);
-  return ce != 0 && pick_bn(d->k) == 208 && (long long)d->kh * d->kw * ce >= 1024;
+  static const int min_kk = getenv("TDG_WDMA_MINKK") ? atoi(getenv("TDG_WDMA_MINKK")) : 128;    // diagnostics
+  return ce != 0 && pick_bn(d->k) == 208 && (long long)d->kh * d->kw * ce >= min_kk;
 }
 
 static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
@@ -2151,15 +2154,16 @@ static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   int want = tdg_ceil_div(768, tiles);                  // register-staged kernel: ~3 workgroups per CU
   if (dma) {
     // one workgroup per CU: the fewest splits (each costs an f32 slab written and re-read) whose last round of
-    // 256 workgroups is within 10 % of the best fill any split count up to 16 reaches
+    // 256 workgroups is within 10 % of the best fill any split count up to 16 (few tiles: up to 256 / tiles) reaches
     static const int force = getenv("TDG_WSPLIT") ? atoi(getenv("TDG_WSPLIT")) : 0;   // diagnostics
     double best = 0.0;
-    for (int sp = 1; sp <= 16; ++sp) {
+    const int sp_max = tiles >= 16 ? 16 : 256 / tiles;    // few tiles: up to one round of splits
+    for (int sp = 1; sp <= sp_max; ++sp) {
       const double fill = (double)tiles * sp / (256.0 * tdg_ceil_div((long long)tiles * sp, 256));
       best = fill > best ? fill : best;
     }
-    want = 16;
-    for (int sp = 1; sp <= 16; ++sp) {
+    want = sp_max;
+    for (int sp = 1; sp <= sp_max; ++sp) {
       const double fill = (double)tiles * sp / (256.0 * tdg_ceil_div((long long)tiles * sp, 256));
       if (fill >= 0.9 * best) { want = sp; break; }
     }
