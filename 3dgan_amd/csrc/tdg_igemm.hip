@@ -1505,6 +1505,182 @@ __global__ void __launch_bounds__(256) pack_fused_kernel(const FusedPackArgs a) 
 }
 
 // ============================================================================================
+// Forward conv of a THIN input (C <= 4 channels: the discriminator's / encoder's first layer on images).  The
+// implicit-GEMM kernels see such an input as 8-channel pixels, i.e. K = taps x 8 padded to 64s (75 real of 256 for
+// 5x5x3: that GEMM is bound by its padded MFMA work).  Here K is compact, k = tap * C + c padded to 32 (75 -> 96):
+// a workgroup stages the input patch of its 128 output pixels (one or more whole output rows of one image, zeros
+// outside the image) and the filter tile [224][K] in LDS; A fragments are gathered from the patch element by
+// element through a k -> patch-offset table, B fragments are 16-byte rows.  4 waves as 2 x 2, 64 pixels x 112
+// columns per wave (7 column tiles; the 14th of the workgroup is spill), LDS-staged 16-byte epilogue.   bf16 only.
+// ============================================================================================
+#define TH_PIX 128
+struct ThinFwdArgs {
+  const bf16_t* x;        // [n][H][W][Cs]
+  const bf16_t* w;        // packed [ntiles_n * 224][WP]
+  bf16_t* y;              // [n][OH][OW][Cso]
+  const float* bias;
+  const bf16_t* mask_src;
+  int H, W, Cs, C;
+  int OH, OW, Cso, N;
+  int KH, KW, stride, pad_t, pad_l;
+  int Kp, WP;             // K padded to 32; filter row pitch (elements, odd number of 16-byte chunks)
+  int TH, tiles_per_image, ntiles_n;
+  int PH, PW;             // staged patch (pixels), 4 elements per pixel
+  int y_off, k_off;       // LDS byte offsets of the patch and of the k table
+  int act, mask_mode;
+  float leak;
+  int debug;              // TDG_DEBUG_ABLATE (diagnostics): 7 = no global stores, 8 = no MFMA loop
+  FastDiv fd_ow, fd_c, fd_pw;
+};
+
+__global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
+  constexpr int BNL = 224, TM = 4, TN = 7;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
+  unsigned short* sP = reinterpret_cast<unsigned short*>(smem + a.y_off);          // patch [PH][PW][4]
+  unsigned short* sK = reinterpret_cast<unsigned short*>(smem + a.k_off);           // k -> patch element offset [Kp]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
+  const int tile_n = blockIdx.x % a.ntiles_n, tile_m = blockIdx.x / a.ntiles_n;
+  const int img = tile_m / a.tiles_per_image, rt = tile_m - img * a.tiles_per_image;
+  const int oy0 = rt * a.TH, n0 = tile_n * 208;
+  const int npix = min(a.TH, a.OH - oy0) * a.OW;
+
+  // ---- stage by LDS-DMA (every load in flight at once; as load / store batches the staging was latency-bound):
+  // filter tile = straight copy in 16-byte chunks; patch = 4-byte pieces (two channels), out-of-image pieces and
+  // the zero element come from out-of-range sources; then the k -> offset table
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w + (size_t)tile_n * BNL * a.WP, (unsigned)(BNL * a.WP * 2));
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.x + (size_t)img * a.H * a.W * a.Cs, (unsigned)(a.H * a.W * a.Cs * 2));
+    const int nvW = BNL * a.WP / 8;
+    for (int g0 = wave * 64; g0 < nvW; g0 += 4 * 64) {
+      const int g = g0 + lane;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lds_ptr_t)(smem + g0 * 16), 16, g < nvW ? (unsigned)g * 16u : OOB_OFFSET, 0, 0, 0);
+    }
+    const int iy0 = oy0 * a.stride - a.pad_t, ix0 = -a.pad_l;
+    const int nP = a.PH * a.PW * 2 + 4;                           // 4-byte pieces incl. the zero element's
+    char* sPb = reinterpret_cast<char*>(sP);
+    for (int g0 = wave * 64; g0 < nP; g0 += 4 * 64) {
+      const int g = g0 + lane;
+      const int p = g >> 1, half = g & 1;
+      const int py = (int)fd_div((unsigned)p, a.fd_pw), px = p - py * a.PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      const bool ok = p < a.PH * a.PW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lds_ptr_t)(sPb + g0 * 4), 4, ok ? (unsigned)(((iy * a.W + ix) * a.Cs + half * 2) * 2) : OOB_OFFSET, 0, 0, 0);
+    }
+    for (int k = tid; k < a.Kp; k += 256) {
+      const int tap = (int)fd_div((unsigned)k, a.fd_c), c = k - tap * a.C;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
+      sK[k] = tap < a.KH * a.KW ? (unsigned short)((kh * a.PW + kw) * 4 + c) : (unsigned short)0xffff;
+    }
+  }
+  __syncthreads();
+
+  const int wm = wave >> 1, wn = wave & 1;
+  // patch element offset of each of this lane's 4 pixels (row r16 of row-fragment i)
+  int pbase[TM];
+  const int zero_off = a.PH * a.PW * 4;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int p = wm * 64 + i * 16 + r16;
+    p = p < npix ? p : 0;
+    const int oy = (int)fd_div((unsigned)p, a.fd_ow), ox = p - oy * a.OW;
+    pbase[i] = (oy * a.stride * a.PW + ox * a.stride) * 4;
+  }
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bf16_t* wrow = sW + (size_t)(wn * 112 + r16) * a.WP + q * 8;
+
+  for (int ks = 0; ks < (a.debug == 8 ? 0 : a.Kp / 32); ++ks) {
+    // this lane's 8 k offsets of the step (the same for every pixel)
+    const i32x4 ko = *reinterpret_cast<const i32x4*>(sK + ks * 32 + q * 8);
+    int off[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const unsigned lo = (unsigned)ko[e] & 0xffffu, hi = (unsigned)ko[e] >> 16;
+      off[2 * e] = lo == 0xffffu ? -1 : (int)lo;
+      off[2 * e + 1] = hi == 0xffffu ? -1 : (int)hi;
+    }
+    bf16x8 fa[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      unsigned pk[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned lo = sP[off[2 * e] < 0 ? zero_off : pbase[i] + off[2 * e]];
+        const unsigned hi = sP[off[2 * e + 1] < 0 ? zero_off : pbase[i] + off[2 * e + 1]];
+        pk[e] = lo | (hi << 16);
+      }
+      const i32x4 t = {(int)pk[0], (int)pk[1], (int)pk[2], (int)pk[3]};
+      fa[i] = __builtin_bit_cast(bf16x8, t);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(wrow + (size_t)j * 16 * a.WP + ks * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();                                        // every wave is done with sW / sP: reuse LDS as the staging tile
+
+  // ---- epilogue: bias + activation into an LDS tile, then whole 16-byte chunks of pixel rows to HBM ----------------
+  constexpr int PE = 208 * 2 + 16, CPR = 208 * 2 / 16;
+  char* sE = smem;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = (wn * TN + j) * 16 + q * 4;
+    if (col >= 208) continue;
+    const int n = n0 + col;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f32x4 v = acc[i][j] + bv;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act, a.leak);
+      *reinterpret_cast<bf16x4*>(sE + (wm * 64 + i * 16 + r16) * PE + col * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+  }
+  __syncthreads();
+  bf16_t* yi = a.y + ((size_t)img * a.OH + oy0) * a.OW * a.Cso;          // the tile's pixels are contiguous rows of y
+  for (int c = tid; c < npix * CPR; c += 256) {
+    const int row = c / CPR, cc = c - row * CPR;
+    const int n = n0 + cc * 8;
+    if (n >= a.N || a.debug == 7) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
+    const size_t o = (size_t)row * a.Cso + n;
+    if (a.mask_mode != TDG_MASK_NONE) {
+      const bf16x8 mv = *reinterpret_cast<const bf16x8*>(a.mask_src + ((size_t)img * a.OH + oy0) * a.OW * a.Cso + o);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], a.mask_mode, a.leak));
+    }
+    *reinterpret_cast<bf16x8*>(yi + o) = v;
+  }
+}
+
+// filter of thin_fwd_kernel from the f32 master [kh][kw][c][k]: rows n (zero beyond N), k = tap * C + c
+struct ThinPackArgs {
+  const float* w;
+  bf16_t* out;
+  int C, N, taps, Kp, WP, rows;
+};
+__global__ void __launch_bounds__(256) pack_thin_kernel(const ThinPackArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.rows * a.WP) return;
+  const int r = i / a.WP, k = i - r * a.WP;
+  const int n = (r / 224) * 208 + (r % 224);              // row r of tile r/224 is output column tile*208 + r%224
+  float v = 0.f;
+  if ((r % 224) < 208 && n < a.N && k < a.taps * a.C) {
+    const int tap = k / a.C, c = k - tap * a.C;
+    v = a.w[((size_t)tap * a.C + c) * a.N + n];
+  }
+  a.out[i] = (bf16_t)v;
+}
+
+// ============================================================================================
 // host side: planning + launch
 // ============================================================================================
 namespace {
@@ -1810,12 +1986,44 @@ bool plan_bwd_fused(const TdgConvDesc* d, FusedPlan* f) {
   return true;
 }
 
+// ---- thin-input forward conv (thin_fwd_kernel): when it applies and its geometry ------------------------------------
+struct ThinPlan {
+  int Kp, WP, TH, tiles_per_image, ntiles_n, PH, PW, y_off, k_off, rows;
+  size_t w_bytes, lds;
+};
+
+bool plan_fwd_thin(const TdgConvDesc* d, ThinPlan* t) {
+  static const int enabled = getenv("TDG_THIN") ? atoi(getenv("TDG_THIN")) : 1;   // diagnostics: 0 = implicit-GEMM kernels
+  if (!enabled || d->dtype != TDG_BF16 || d->c > 4 || d->cs < 4 || (d->cs & 3) || (d->k & 7) || (d->ks & 7)) return false;
+  if (d->ow > TH_PIX || d->k < 160) return false;              // narrow outputs waste the 208-column tile: implicit GEMM
+  t->Kp = (int)tdg_round_up((long long)d->kh * d->kw * d->c, 32);
+  if (t->Kp > 256) return false;
+  t->WP = ((t->Kp / 8) & 1) ? t->Kp : t->Kp + 8;               // odd number of 16-byte chunks per filter row
+  t->TH = TH_PIX / d->ow;
+  if (t->TH > d->oh) t->TH = d->oh;
+  t->tiles_per_image = tdg_ceil_div(d->oh, t->TH);
+  t->ntiles_n = tdg_ceil_div(d->k, 208);
+  t->PH = (t->TH - 1) * d->stride + d->kh;
+  t->PW = (d->ow - 1) * d->stride + d->kw;
+  if ((long long)t->PH * t->PW * 4 + 8 > 0xfff0) return false; // 16-bit patch offsets
+  t->rows = t->ntiles_n * 224;
+  t->w_bytes = (size_t)t->rows * t->WP * 2;
+  t->y_off = (int)tdg_round_up((long long)224 * t->WP * 2, 1024);               // + the zero-filled tail of the last filter DMA
+  t->k_off = t->y_off + (int)tdg_round_up(((long long)t->PH * t->PW * 2 + 4) * 4, 256);   // + the tail of the last patch DMA
+  const size_t main = (size_t)t->k_off + (size_t)t->Kp * 2 + 16;
+  const size_t epi = (size_t)TH_PIX * (208 * 2 + 16);
+  t->lds = main > epi ? main : epi;
+  return t->lds <= 80 * 1024;                                  // two workgroups per CU
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t tdg_packed_filter_fwd_bytes(const TdgConvDesc* d) {
   if (validate_desc(d, "tdg_packed_filter_fwd_bytes") != TDG_OK) return 0;
+  ThinPlan tp;
+  if (plan_fwd_thin(d, &tp)) return tp.w_bytes;
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
   int ce = eff_channels(d->c, d->cs, vec);
   if (!ce) ce = d->c;
@@ -1906,10 +2114,22 @@ static int launch_pack_fused(const TdgConvDesc* d, const FusedPlan& fp, const fl
   return TDG_OK;
 }
 
+static int launch_pack_thin(const TdgConvDesc* d, const ThinPlan& tp, const float* w, void* packed, hipStream_t s) {
+  ThinPackArgs a;
+  a.w = w;
+  a.out = static_cast<bf16_t*>(packed);
+  a.C = d->c; a.N = d->k; a.taps = d->kh * d->kw; a.Kp = tp.Kp; a.WP = tp.WP; a.rows = tp.rows;
+  hipLaunchKernelGGL(pack_thin_kernel, dim3(tdg_ceil_div((long long)tp.rows * tp.WP, 256)), dim3(256), 0, s, a);
+  TDG_HIP_LAUNCH_CHECK("pack_filter_fwd(thin)");
+  return TDG_OK;
+}
+
 int tdg_pack_filter_fwd(const TdgConvDesc* d, const float* w, void* packed, void* stream) {
   int rc = validate_desc(d, "tdg_pack_filter_fwd");
   if (rc) return rc;
   TDG_CHECK_ARG(w && packed, "tdg_pack_filter_fwd: null pointer");
+  ThinPlan tp;
+  if (plan_fwd_thin(d, &tp)) return launch_pack_thin(d, tp, w, packed, (hipStream_t)stream);
   PackArgs a;
   build_pack_fwd(d, w, packed, &a);
   return launch_pack_one(a, d->dtype, (hipStream_t)stream);
@@ -1963,10 +2183,16 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
     TDG_CHECK_ARG(d->dtype == dtype, "tdg_pack_filters: job %d has dtype %d, job 0 has %d", j, d->dtype, dtype);
     TDG_CHECK_ARG(jobs[j].w, "tdg_pack_filters: job %d has no master filter", j);
     if (jobs[j].packed_fwd) {
-      PackArgs a;
-      build_pack_fwd(d, jobs[j].w, jobs[j].packed_fwd, &a);
-      rc = push(a);
-      if (rc) return rc;
+      ThinPlan tp;
+      if (plan_fwd_thin(d, &tp)) {
+        rc = launch_pack_thin(d, tp, jobs[j].w, jobs[j].packed_fwd, (hipStream_t)stream);
+        if (rc) return rc;
+      } else {
+        PackArgs a;
+        build_pack_fwd(d, jobs[j].w, jobs[j].packed_fwd, &a);
+        rc = push(a);
+        if (rc) return rc;
+      }
     }
     if (jobs[j].packed_bwd) {
       FusedPlan fp;
@@ -2008,6 +2234,39 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   const bool veca = ce != 0;
   const int C = veca ? ce : d->c;
   TDG_CHECK_ARG(!veca || ((uintptr_t)x & 15) == 0, "tdg_conv2d_fwd: x must be 16-byte aligned (channel stride allows the vector gather)");
+  ThinPlan tp;
+  if (plan_fwd_thin(d, &tp) && !(epi && epi->accumulate)) {
+    ThinFwdArgs f;
+    memset(&f, 0, sizeof(f));
+    f.x = static_cast<const bf16_t*>(x);
+    f.w = static_cast<const bf16_t*>(wp);
+    f.y = static_cast<bf16_t*>(y);
+    f.bias = epi ? epi->bias : nullptr;
+    f.act = epi ? epi->act : TDG_ACT_NONE;
+    f.leak = epi ? epi->leak : 0.f;
+    f.mask_mode = epi ? epi->mask_mode : TDG_MASK_NONE;
+    f.mask_src = f.mask_mode != TDG_MASK_NONE ? static_cast<const bf16_t*>(epi->mask_src) : nullptr;
+    f.H = d->h; f.W = d->w; f.Cs = d->cs; f.C = d->c;
+    f.OH = d->oh; f.OW = d->ow; f.Cso = d->ks; f.N = d->k;
+    f.KH = d->kh; f.KW = d->kw; f.stride = d->stride; f.pad_t = d->pad_t; f.pad_l = d->pad_l;
+    f.Kp = tp.Kp; f.WP = tp.WP; f.TH = tp.TH; f.tiles_per_image = tp.tiles_per_image; f.ntiles_n = tp.ntiles_n;
+    f.PH = tp.PH; f.PW = tp.PW; f.y_off = tp.y_off; f.k_off = tp.k_off;
+    f.fd_pw = make_fastdiv(tp.PW);
+    f.fd_ow = make_fastdiv(d->ow);
+    f.fd_c = make_fastdiv(d->c);
+    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_set = true;
+    }
+    tdg_note_kernel("thin_fwd_kernel<bf16>");
+    tdg_timing_start("thin_fwd_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
+    hipLaunchKernelGGL(thin_fwd_kernel, dim3(n_images * tp.tiles_per_image * tp.ntiles_n), dim3(256), tp.lds, (hipStream_t)stream, f);
+    tdg_timing_stop((hipStream_t)stream);
+    TDG_HIP_LAUNCH_CHECK("thin_fwd");
+    return TDG_OK;
+  }
   IgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x;

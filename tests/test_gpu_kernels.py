@@ -38,6 +38,9 @@ CONV_CASES = [
     (2, 16, 16, 3, 100, 5, 2),     # dc4 geometry: big side c=3 (scalar), small side 100 -> stride 104
     (3, 7, 9, 3, 24, 5, 2),        # thin big side, odd sizes: fused-class backward-data with ragged parity classes
     (2, 32, 32, 1, 40, 5, 2),      # one channel (mnist): fused-class backward-data, row-tiled
+    (3, 32, 32, 3, 200, 5, 2),     # c1 itself: thin-input forward kernel (compact K = 75 -> 96), 16 x 16 output, N = 200
+    (2, 64, 64, 3, 64, 5, 2),      # VAE / autoencoder c1: thin-input forward, 4 output rows per workgroup
+    (2, 12, 20, 2, 232, 3, 1),     # thin input, stride 1, two column tiles, ragged last row tile
 ]
 
 
