@@ -230,8 +230,8 @@ class GanReplica(engine.GraphRunner):
             self._run('d_grads_a', self._d_grads_a)
             work = sess.allreduce_async(store.grads[lo:hi])
             self._run('d_grads_b', self._d_grads_b)
-            sess.assert_finite(store, 'd_step')
             work.wait()
+            sess.assert_finite(store, 'd_step')                       # (sums over replicas: NaN/Inf survive the exchange)
             if lo > 0:
                 sess.allreduce_mean_scale(store.grads[:lo])
             if hi < store.size:
