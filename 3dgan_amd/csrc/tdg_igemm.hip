@@ -610,7 +610,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     // barrier.  Raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA.
     auto wait_barrier = [&](bool more_in_flight) {
       if (more_in_flight) {
-        static_assert(LD::NP >= 4 && LD::NP <= 8, "add the immediate");
+        static_assert(LD::NP >= 3 && LD::NP <= 8, "add the immediate");
+        if constexpr (LD::NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         if constexpr (LD::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr (LD::NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         if constexpr (LD::NP == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
@@ -1780,12 +1781,18 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
     return launch_fwd_dma<T, 256, 208, 2>(a, mmax, s);
   }
-  // 65..112 columns (the generator's 100-channel layers): the same kernel with a 7-tile-wide column tile
-  if (veca && bn == 128 && a.N <= 112 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
-    const long long t256 = (long long)a.nclasses * tdg_ceil_div(mmax, 256), t128 = (long long)a.nclasses * tdg_ceil_div(mmax, 128);
+  // 128-column problems (pix2pix / VAE widths 128, 256, 512, 1024) and 65..112 columns (the generator's 100-channel
+  // layers, a 7-tile-wide column tile): the same LDS-DMA kernel, 3-stage ring at every row tile
+  if (veca && bn == 128 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
+    const int bnt = a.N <= 112 ? 112 : 128;
+    const long long per = (long long)tdg_ceil_div(a.N, bnt) * a.nclasses;
+    const long long t256 = per * tdg_ceil_div(mmax, 256), t128 = per * tdg_ceil_div(mmax, 128);
     const double c256 = (double)tdg_ceil_div(t256, 256) * 256, c128 = (double)tdg_ceil_div(t128, 256) * 128 / 0.85;
-    return c128 < c256 ? launch_fwd_dma<T, 128, 112, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 112, 3>(a, mmax, s);
+    if (bnt == 112) return c128 < c256 ? launch_fwd_dma<T, 128, 112, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 112, 3>(a, mmax, s);
+    return c128 < c256 ? launch_fwd_dma<T, 128, 128, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 128, 3>(a, mmax, s);
   }
+  // 64-column problems: 128-row tile (3 loader pieces per wave on 4 column tiles)
+  if (veca && bn == 64 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0 && a.N > 32) return launch_fwd_dma<T, 128, 64, 3>(a, mmax, s);
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   int gx = a.ntiles_n * a.ntiles_m_max;
@@ -1823,17 +1830,20 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
   return TDG_OK;
 }
 
-int launch_wgrad_dma208(WgArgs& a, hipStream_t s) {
+template <int BN>
+int launch_wgrad_dma(WgArgs& a, hipStream_t s) {
   const size_t lds = 4 * (size_t)WD_MR * WD_ROWB + IG_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<208>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d>", BN);
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
-  tdg_note_kernel("igemm_wgrad_dma_kernel<bf16,256,208>");
-  tdg_timing_start("igemm_wgrad_dma_kernel<bf16,256,208>", t_flops, s);
-  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<208>), grid, block, lds, s, a);
+  tdg_note_kernel(name);
+  tdg_timing_start(name, t_flops, s);
+  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN>), grid, block, lds, s, a);
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad_dma");
   return TDG_OK;
@@ -2399,7 +2409,8 @@ static bool wgrad_use_dma(const TdgConvDesc* d) {
   if (d->dtype != TDG_BF16) return false;
   const int ce = eff_channels(d->c, d->cs, 8);
   static const int min_kk = getenv("TDG_WDMA_MINKK") ? atoi(getenv("TDG_WDMA_MINKK")) : 128;    // diagnostics
-  return ce != 0 && pick_bn(d->k) == 208 && (long long)d->kh * d->kw * ce >= min_kk;
+  const int bn = pick_bn(d->k);
+  return ce != 0 && (bn == 208 || (bn == 128 && d->k > 112)) && (long long)d->kh * d->kw * ce >= min_kk;
 }
 
 static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
@@ -2513,7 +2524,7 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
   t_flops = conv_flops(d, n_images);
-  rc = dma ? launch_wgrad_dma208(a, (hipStream_t)stream)
+  rc = dma ? (bn == 208 ? launch_wgrad_dma<208>(a, (hipStream_t)stream) : launch_wgrad_dma<128>(a, (hipStream_t)stream))
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
