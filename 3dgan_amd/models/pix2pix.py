@@ -45,7 +45,7 @@ class ModelPlugin:
         raise NotImplementedError
 
 
-class pix2pix(ModelPlugin):
+class pix2pix(ModelPlugin, engine.GraphRunner):
     name = 'pix2pix'
 
     @staticmethod
@@ -158,6 +158,7 @@ class pix2pix(ModelPlugin):
         self.x_stage = torch.zeros(B, H, W, 3, dtype=torch.float32, device=dev)
         self.y_stage = torch.zeros(B, H, W, 1, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.init_graphs(args, sess)               # the step bodies below are captured into hipGraphs and replayed
         self.refresh()
 
     # ---- variables -----------------------------------------------------------------------------------
@@ -187,16 +188,23 @@ class pix2pix(ModelPlugin):
         return d
 
     # ---- pieces ------------------------------------------------------------------------------------------
-    def _load(self, batch):
-        """hem.rescale((0,1) -> (-1,1)) of both halves (hem/models/pix2pix.py:103-104) into D's input slots."""
+    def _stage(self, batch):
+        """The batch at fixed device addresses (the step bodies may be graph-captured)."""
         x01, y01 = batch
-        B, dt = self.B, self.sess.dtype
         self.x_stage.copy_(x01.reshape(self.x_stage.shape))
         self.y_stage.copy_(y01.reshape(self.y_stage.shape))
+
+    def _rescale(self):
+        """hem.rescale((0,1) -> (-1,1)) of both halves (hem/models/pix2pix.py:103-104) into D's input slots."""
+        B, dt = self.B, self.sess.dtype
         rows, cs = B * 256 * 256, self.D.x.cs
         for img0 in (0, B):
             _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, cs, 2.0, -0.5, self.D.x.ptr(img0), K.stream())
         _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.y_stage), rows, 1, cs, 2.0, -0.5, self.D.x.window(3, 1).ptr(0), K.stream())
+
+    def _load(self, batch):
+        self._stage(batch)
+        self._rescale()
 
     def _d_forward(self, first, count):
         B = self.B
@@ -224,8 +232,16 @@ class pix2pix(ModelPlugin):
 
     # ---- steps ---------------------------------------------------------------------------------------------
     def d_step(self, batch):
+        self._stage(batch)
+        self._run('d_grads', self._d_grads)
+        self.sess.assert_finite(self.d_store, 'd_step')
+        self._scale = average_gradients(self.sess, self.d_store)      # RCCL, outside the graphs
+        self._run('d_apply', self._d_apply)
+        self.sess.global_step += 1
+
+    def _d_grads(self):
         B = self.B
-        self._load(batch)
+        self._rescale()
         self.U.forward()
         self._d_forward(0, 2)
         self._xent(1)
@@ -234,14 +250,22 @@ class pix2pix(ModelPlugin):
             self.D.backward(B, B, bn_pass=1, want_params=True, acc=True)
         else:
             self.D.backward(0, 2 * B, want_params=True)
-        self.sess.assert_finite(self.d_store, 'd_step')
-        self.d_opt.step(average_gradients(self.sess, self.d_store))
-        self.sess.global_step += 1
+
+    def _d_apply(self):
+        self.d_opt.step(self._scale)
         self.D.repack()
 
     def g_step(self, batch):
+        self._stage(batch)
+        self._run('g_grads', self._g_grads)
+        self.sess.assert_finite(self.g_store, 'g_step')
+        self._scale = average_gradients(self.sess, self.g_store)
+        self._run('g_apply', self._g_apply)
+        self.sess.global_step += 1
+
+    def _g_grads(self):
         B = self.B
-        self._load(batch)
+        self._rescale()
         self.U.forward()
         self._d_forward(0, 2)                  # both passes: with batch norm the statistics are per pass anyway
         self._xent(2)
@@ -252,18 +276,22 @@ class pix2pix(ModelPlugin):
         if self.args.add_l1:
             self._l1(True)
         self.U.backward()
-        self.sess.assert_finite(self.g_store, 'g_step')
-        self.g_opt.step(average_gradients(self.sess, self.g_store))
-        self.sess.global_step += 1
+
+    def _g_apply(self):
+        self.g_opt.step(self._scale)
         self.U.repack()
 
-    def report(self, batch):
-        """sess.run(all_losses) on a third batch (hem/models/pix2pix.py:155)."""
-        self._load(batch)
+    def _report_body(self):
+        self._rescale()
         self.U.forward()
         self._d_forward(0, 2)
         self._xent(0)
         self._l1(False)
+
+    def report(self, batch):
+        """sess.run(all_losses) on a third batch (hem/models/pix2pix.py:155)."""
+        self._stage(batch)
+        self._run('report', self._report_body)
         s = self.scal.cpu().tolist()
         r = self.sess.rank
         g_total = s[self.S_GFAKE] + (L1_WEIGHT * s[self.S_L1] if self.args.add_l1 else 0.0)
