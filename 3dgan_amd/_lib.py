@@ -82,6 +82,7 @@ SIGNATURES = {
     'tdg_vae_reparam_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     'tdg_vae_kl': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'tdg_vae_bce': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'tdg_dropout': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp]),
     'tdg_l1_loss': (_i, [_i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'tdg_gp_scalars': (_i, [_vp, _f, _vp, _vp]),
     'tdg_scale_by_dev': (_i, [_i, _vp, _sz, _vp, _vp, _vp]),

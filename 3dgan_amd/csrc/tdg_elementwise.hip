@@ -915,6 +915,28 @@ extern "C" int tdg_l1_loss(int dtype, const float* x, const void* d, int rows, i
   return TDG_OK;
 }
 
+// tf.nn.dropout(x, keep_prob) given the uniform draws u: x * floor(keep_prob + u) / keep_prob, in place.  The same call
+// with the same u on the incoming gradient is its backward.
+template <typename T>
+__global__ void __launch_bounds__(256) dropout_kernel(T* __restrict__ y, size_t n, int c, int ycs, const float* __restrict__ u,
+                                                     float keep, float inv_keep) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / c;
+    const size_t j = r * ycs + (i - r * c);
+    y[j] = from_f32<T>(to_f32<T>(y[j]) * floorf(keep + u[i]) * inv_keep);
+  }
+}
+extern "C" int tdg_dropout(int dtype, void* y, int rows, int c, int ycs, const float* u, float keep, void* stream) {
+  TDG_CHECK_ARG(y && u && rows > 0 && c > 0 && ycs >= c && keep > 0.f && keep <= 1.f, "tdg_dropout: bad argument");
+  const size_t n = (size_t)rows * c;
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(dropout_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, static_cast<T*>(y), n, c, ycs, u,
+                       keep, 1.f / keep);
+  })
+  TDG_HIP_LAUNCH_CHECK("dropout");
+  return TDG_OK;
+}
+
 __global__ void gp_scalars_kernel(const float* __restrict__ ss, float lambda, float* __restrict__ scal) {
   const float s = sqrtf(ss[0]);
   scal[0] = (s - 1.f) * (s - 1.f);

@@ -226,6 +226,9 @@ class SeqNet:
         self.dx = K.Act(capacity, h, w, c, dtype, device) if need_input_grad else None
         self.layers = []
         prev = self.x
+        for spec in net.layers:
+            if getattr(spec, 'dropout', 0):
+                raise NotImplementedError('layer %s: dropout is only executed by the pix2pix U-Net (models/pix2pix.py)' % spec.name)
         prev_g = self.dx
         cum = 1
         for idx, spec in enumerate(net.layers):

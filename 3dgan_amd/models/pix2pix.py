@@ -14,7 +14,8 @@ pass the encoder's two gradient paths (next encoder layer + skip) are summed by 
 the backward-data GEMM; D(x,y) and D(x,G(x)) run as one batched pass over [x|y ; x|g]; G(x) lands directly
 in channel 3 of D's input and dL/dG(x) is read from channel 3 of D's input gradient.
 
-Not available: `--dropout > 0`, `--noise` (both default off in the reference's configs).
+`--dropout` (keep probability of decoder layers 1-3, hem/models/pix2pix.py:204-208) is executed by the U-Net below.
+Not available: `--noise` (off in the reference's configs).
 """
 import torch
 
@@ -148,7 +149,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         self.U = UNet(self.enet, self.dec_net, B, H, W, dt, dev, self.g_store, self.ws,
                       x_in=self.D.x.view(0, B).window(0, 3),
                       g_out=self.D.x.view(B, B).window(3, 1),
-                      g_grad=self.D.dx.view(B, B).window(3, 1))
+                      g_grad=self.D.dx.view(B, B).window(3, 1), sess=sess)
         self.d_store.allocate()
         self.g_store.allocate()
         gen = torch.Generator().manual_seed(sess.seed)
@@ -321,8 +322,9 @@ class UNet:
     first, main path accumulated on top -- in the right window of gcat[9-k].
     """
 
-    def __init__(self, enet, dnet, B, H, W, dtype, device, store, ws, x_in, g_out, g_grad):
+    def __init__(self, enet, dnet, B, H, W, dtype, device, store, ws, x_in, g_out, g_grad, sess=None):
         self.B, self.dtype, self.device, self.store, self.ws = B, dtype, device, store, ws
+        self.sess = sess
         self.enet, self.dnet = enet, dnet
         E, Dc = enet.layers, dnet.layers
         assert len(E) == 8 and len(Dc) == 8
@@ -375,6 +377,11 @@ class UNet:
             small = self.e_h[8] if i == 1 else self.cat[i]
             self.d_conv[i] = K.Conv(self.d_pre[i], small, spec.k, spec.k, spec.stride, 1, 1)
         self.d_stats = {i: torch.zeros(2 * Dc[i - 1].out_size, dtype=torch.float32, device=device) for i in range(1, 9)}
+        # tf.nn.dropout(h, keep_prob=dropout) on decoder layers built with dropout > 0 (hem/models/pix2pix.py:204-208,
+        # hem/ops/layers.py:207): the uniform draws of the pass, kept for the backward
+        self.d_keep = {i: float(getattr(Dc[i - 1], 'dropout', 0) or 0) for i in range(1, 9)}
+        self.d_u = {i: torch.zeros(B * self.d_pre[i].h * self.d_pre[i].w * Dc[i - 1].out_size, dtype=torch.float32, device=device)
+                    for i in range(1, 9) if self.d_keep[i] > 0}
         self.e_stats = {k: torch.zeros(2 * E[k - 1].out_size, dtype=torch.float32, device=device) for k in range(1, 9)}
         # variables
         nb = 0
@@ -425,6 +432,14 @@ class UNet:
             conv.bwd_data(src.ptr(), self.d_pre[i].ptr(), B, K.epilogue(bias=st[self.dnet.var_name(spec, 'bias')]))
             K.bn_fwd(self.ws, self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], spec.act.code, self.d_pre[i], self.d_h[i],
                      self.d_stats[i], leak=spec.act.leak)
+            if self.d_keep[i] > 0:
+                self.sess.random_uniform(self.d_u[i], self.d_u[i].numel(), 'dropout')
+                self._dropout(self.d_h[i], i)
+
+    def _dropout(self, act, i):
+        rows = self.B * act.h * act.w
+        _lib.call('tdg_dropout', self.dtype, act.ptr(), rows, self.dnet.layers[i - 1].out_size, act.cs, K.ptr(self.d_u[i]),
+                  self.d_keep[i], K.stream())
 
     # ---- backward from dL/dG(x) in g_grad -------------------------------------------------------------------------
     def backward(self):
@@ -432,6 +447,8 @@ class UNet:
         E, Dc = self.enet.layers, self.dnet.layers
         for i in range(8, 0, -1):
             spec, conv = Dc[i - 1], self.d_conv[i]
+            if self.d_keep[i] > 0:
+                self._dropout(self.d_g[i], i)                                     # d(dropout)/dh = the same mask / keep
             K.bn_bwd(self.ws, self.d_g[i], self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], self.d_stats[i], spec.act.code,
                      self.d_delta[i], g(self.d_bn_name[i]), leak=spec.act.leak)
             K.bias_grad(self.ws, self.d_delta[i], spec.out_size, g(self.dnet.var_name(spec, 'bias')))

@@ -242,13 +242,13 @@ def deconv2d(x, input_size, output_size, filter_size=3, stride=2, init='xavier',
              activation=None, reuse=False, name=None, output_shape=None, dropout=0, use_batch_renorm=False,
              use_instance_norm=False, padding='SAME'):
     """ops/layers.py:111-148 (gen-2: hem/ops/layers.py:138-211): tf.nn.conv2d_transpose SAME, output = 2 x input."""
-    _reject_unsupported(name, dropout, use_batch_renorm, use_instance_norm)
+    _reject_unsupported(name, 0, use_batch_renorm, use_instance_norm)        # dropout: recorded; the executor decides
     if output_shape is not None or padding != 'SAME':
         raise NotImplementedError('deconv2d %s: explicit output_shape / VALID padding are only used by the thesis models' % name)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('deconv2d %s: input has %d channels, expected %d' % (name, c, input_size))
     spec = LayerSpec('deconv2d', name, input_size, output_size, filter_size, stride, use_batch_norm, activation,
-                     (h, w, c), (h * 2, w * 2, output_size), 'SAME', init)
+                     (h, w, c), (h * 2, w * 2, output_size), 'SAME', init, dropout=dropout)
     current_net().add(spec, reuse)
     return Sym((None, h * 2, w * 2, output_size), producer=spec)

@@ -224,6 +224,10 @@ int tdg_vae_bce(int dtype, const float* x, const void* d, int rows, int c, int c
  * x: compact f32 [rows, c]; d, seed: [rows, cs] in dtype. */
 int tdg_l1_loss(int dtype, const float* x, const void* d, int rows, int c, int cs, float scale, float shift, void* seed,
                 float* scal, void* workspace, size_t workspace_bytes, void* stream);
+/* tf.nn.dropout(y, keep_prob) (hem/ops/layers.py:207) given the uniform draws u [rows, c] (compact f32):
+ * y = y * floor(keep_prob + u) / keep_prob, in place on [rows, ycs]-strided y.  Applied to the incoming gradient with
+ * the same u it is the layer's backward. */
+int tdg_dropout(int dtype, void* y, int rows, int c, int ycs, const float* u, float keep, void* stream);
 /* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
  * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);

@@ -59,8 +59,10 @@ def init_params(args, seed=0, dtype=np.float32):
             for k, s in param_shapes(args).items()}
 
 
-def generator(P, x, args):
-    """x: [B,256,256,3] in [-1,1] -> [B,256,256,1] (tanh)."""
+def generator(P, x, args, drops=None):
+    """x: [B,256,256,3] in [-1,1] -> [B,256,256,1] (tanh).  `drops`: the uniform draws [B,h,w,512] of the dropout on
+    decoder layers 1-3 (hem/models/pix2pix.py:204-208 `dropout=args.dropout`; hem/ops/layers.py:207
+    `tf.nn.dropout(h, keep_prob=dropout)` = h * floor(keep_prob + u) / keep_prob, after the activation)."""
     e, h, nb = [], x, 0
     for i in range(1, 9):
         h = TR.conv2d_same(h, P['generator/enocder/vars/%d/weights' % i], 2) + P['generator/enocder/vars/%d/bias' % i]
@@ -76,6 +78,8 @@ def generator(P, x, args):
         y = TR.conv2d_transpose_same(y, P['generator/decoder/vars/%d/weights' % i]) + P['generator/decoder/vars/%d/bias' % i]
         y = TR.batch_norm(y, P[_bn('generator/decoder', i - 1)])
         y = torch.tanh(y) if i == 8 else torch.relu(y)
+        if i <= 3 and getattr(args, 'dropout', 0) > 0:
+            y = y * torch.floor(args.dropout + drops[i - 1]) / args.dropout
     return y
 
 

@@ -41,6 +41,9 @@ CONV_CASES = [
     (3, 32, 32, 3, 200, 5, 2),     # c1 itself: thin-input forward kernel (compact K = 75 -> 96), 16 x 16 output, N = 200
     (2, 64, 64, 3, 64, 5, 2),      # VAE / autoencoder c1: thin-input forward, 4 output rows per workgroup
     (2, 12, 20, 2, 232, 3, 1),     # thin input, stride 1, two column tiles, ragged last row tile
+    (2, 64, 64, 1, 128, 4, 2),     # pix2pix d8 (deconv 128 -> 1): one-channel big side, 128-column LDS-DMA tile
+    (3, 32, 32, 64, 128, 4, 2),    # pix2pix e2 / m2: 128-column LDS-DMA tile, 64-channel input
+    (2, 16, 16, 128, 256, 4, 2),   # 256 columns = two 128-column tiles
 ]
 
 

@@ -142,3 +142,52 @@ def test_pix2pix_bf16_train_runs():
     model = pkg('models').get_model('pix2pix')(PairSource(pairs, dev), args, sess)
     out = model.train(sess, args, None)
     assert set(out) == {'l1', 'add', 'total', 'd_real', 'd_fake', 'rmse'} and all(np.isfinite(v) for v in out.values())
+
+
+def test_pix2pix_dropout_forward_and_backward_f32():
+    """`--dropout 0.5` (examples/pix2pix/baseline.config): tf.nn.dropout(h, keep_prob) on decoder layers 1-3 with injected
+    uniform draws -- G(x) and the U-Net's parameter gradients from an injected dL/dG(x) against the float64 oracle."""
+    p2p, rt, K = pkg('models.pix2pix'), pkg('runtime'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    B, keep = 2, 0.5
+    args = SimpleNamespace(model='pix2pix', batch_size=B, n_gpus=1, optimizer='rmsprop', lr=1e-4, decay=0.9, momentum=0.01,
+                           centered=False, beta1=0.5, beta2=0.999, n_disc_train=1, add_l1=False, batch_norm_gen=True,
+                           batch_norm_disc=False, dropout=keep, noise=[])
+    P0 = PR.init_params(args, 0, np.float32)
+    rng = np.random.default_rng(5)
+    x01 = rng.uniform(0, 1, (B, 256, 256, 3)).astype(np.float32)
+    y01 = rng.uniform(0.01, 0.99, (B, 256, 256, 1)).astype(np.float32)
+    drops = [rng.uniform(0, 1, (B, 2 << i, 2 << i, 512)).astype(np.float32) for i in range(3)]
+    seed = rng.standard_normal((B, 256, 256, 1)).astype(np.float32) * 1e-3
+    sess = rt.Session(device=dev, dtype=K.F32, seed=0, rank=0, world_size=1)
+    model = p2p.pix2pix(PairSource([(x01, y01)], dev), args, sess)
+    model.load_variables(P0)
+    P = TR.to_torch(P0, torch.float64)
+    x = torch.tensor(2 * x01.astype(np.float64) - 1)
+    g = PR.generator(P, x, args, [torch.tensor(d, dtype=torch.float64) for d in drops])
+    gkeys = [k for k in P if k.startswith('generator/')]
+    ref = dict(zip(gkeys, torch.autograd.grad(g, [P[k] for k in gkeys], grad_outputs=torch.tensor(seed, dtype=torch.float64))))
+    P32 = TR.to_torch(P0, torch.float32)
+    g32 = PR.generator(P32, x.float(), args, [torch.tensor(d) for d in drops])
+    ref32 = dict(zip(gkeys, torch.autograd.grad(g32, [P32[k] for k in gkeys], grad_outputs=torch.tensor(seed))))
+
+    model._load((torch.tensor(x01, device=dev), torch.tensor(y01, device=dev)))
+    sess.inject = {'dropout': [d for d in drops]}
+    model.U.forward()
+    assert not sess.inject.get('dropout')                      # all three draws consumed, in layer order
+    slot1 = model.D.x.view(B, B).buf[:B * 256 * 256 * 8].view(B, 256, 256, 8)
+    assert np.abs(slot1[..., 3].cpu().numpy() - g.detach().numpy()[..., 0]).max() < 5e-4
+    dx1 = model.D.dx.view(B, B).buf[:B * 256 * 256 * 8].view(B, 256, 256, 8)
+    dx1.zero_()
+    dx1[..., 3] = torch.tensor(seed[..., 0], device=dev)
+    model.U.backward()
+    got = model.gradients()
+    for k, v in ref.items():
+        if k.endswith('/bias') and ('decoder' in k or not k.endswith('/1/bias')):
+            continue                                            # biases feeding batch norm
+        # l2 only: with a white-noise dL/dG(x) a float32 difference in a pre-activation near zero flips a relu unit of
+        # the 2-sample bottleneck layers and moves isolated filter entries by 10-20 % in ANY float32 implementation
+        # (torch's own float32 run: max-norm 5e-2, l2 4e-3 from its float64 run on the same inputs); a wrong mask or a
+        # missing 1/keep would be O(1) in l2
+        tol2 = max(1e-2, 5.0 * l2err(ref32[k].double().numpy(), v.numpy()))
+        assert l2err(got[k], v.numpy()) < tol2, (k, tol2, l2err(got[k], v.numpy()))
