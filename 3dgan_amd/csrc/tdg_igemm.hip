@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   if constexpr (sizeof(T) == 2) {
     // bf16: stage the tile through the (now idle) LDS ring so that global stores (and mask loads) are whole
     // 16-byte chunks of contiguous pixel rows instead of 8-byte pieces scattered over 16 pixels per instruction
-    if (!accum && (N & 7) == 0) {
+    if (!accum && (N & 3) == 0) {                            // (N % 8 == 4: the last chunk of a row is an 8-byte piece)
       constexpr int PE = BN * 2 + 16;                          // row pitch: +16 B keeps the 8-byte writes spread over banks
       constexpr int CPR = BN * 2 / 16;                         // 16-byte chunks per row
       static_assert(BM * PE + BM * 8 <= NS * STAGE, "epilogue staging must fit the ring");
@@ -717,12 +717,22 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
         const int n = n0 + cc * 8;
         if (p < 0 || n >= N) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
-        if (mmode != TDG_MASK_NONE) {
-          const bf16x8 mv = *reinterpret_cast<const bf16x8*>(msk + p + n);
+        if (n + 8 <= N) {
+          if (mmode != TDG_MASK_NONE) {
+            const bf16x8 mv = *reinterpret_cast<const bf16x8*>(msk + p + n);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], mmode, leak));
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], mmode, leak));
+          }
+          *reinterpret_cast<bf16x8*>(out + p + n) = v;
+        } else {                                               // 4 columns left
+          bf16x4 h = {v[0], v[1], v[2], v[3]};
+          if (mmode != TDG_MASK_NONE) {
+            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + p + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (bf16_t)((float)h[e] * mask_factor((float)mv[e], mmode, leak));
+          }
+          *reinterpret_cast<bf16x4*>(out + p + n) = h;
         }
-        *reinterpret_cast<bf16x8*>(out + p + n) = v;
       }
       return;
     }
