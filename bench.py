@@ -169,7 +169,8 @@ def main():
         ms = dt / args.steps * 1e3
         value = args.steps * args.batch_size * args.gpus / dt
         out = {
-            'metric': 'images/sec (whole node), CIFAR-10 IWGAN bs=512', 'value': value, 'unit': 'images/sec',
+            'metric': 'images/sec (whole node), CIFAR-10 %s bs=%d' % (args.model.upper(), args.batch_size), 'value': value,
+            'unit': 'images/sec',
             'n_gpus': args.gpus, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic (uint8 U{0..255}/255 images, xavier-uniform random-init weights, on-device Philox z/alpha)',
