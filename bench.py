@@ -179,7 +179,7 @@ def main():
                                    'optimizer steps on 6 fresh batches' % (args.model, args.batch_size, args.latent_size),
                        'global_batch': args.batch_size * args.gpus, 'parallelism': 'dp%d' % args.gpus,
                        'consumed_images_per_sec': value * 6,
-                       'step_tflops': value / args.gpus * GFLOP_PER_IMAGE_ITERATION / 1e3,
+                       'step_tflops': (value / args.gpus * GFLOP_PER_IMAGE_ITERATION / 1e3) if args.model == 'iwgan' else None,
                        'final_losses': status},
         }
         if timer:
