@@ -342,3 +342,51 @@ def test_bwd_filter_two_sources(case, dtype):
     conv.bwd_filter2(first.ptr(), n_first, second.ptr(), small.ptr(), dw, n, beta=0.5)
     ref = 0.5 * dw0 + T.conv2d_backprop_filter(x.astype(np.float64), (k, k, cin, cout), dy.astype(np.float64), s)
     assert relerr(dw.cpu().numpy(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', [(3, 32, 32, 3, 200, 5, 2), (2, 16, 16, 200, 400, 5, 2), (2, 20, 12, 4, 168, 3, 1)])
+def test_conv_fwd_with_mask_epilogue(case, dtype):
+    """Forward conv whose epilogue multiplies by the (l)relu derivative of a mask tensor laid out like the output: the
+    tangent pass of the gradient penalty (t_i = lrelu'(h_i) * conv_i(t_{i-1}), no bias).  Covers the thin-input kernel
+    (first case, bf16) and the LDS-DMA kernel."""
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev)
+    m = rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32)
+    if dtype == 1:
+        x, Wt, m = bf16_round(x), bf16_round(Wt), bf16_round(m)
+    conv.pack(torch.tensor(Wt, device=dev))
+    big.set(x)
+    mask = small.like().set(m)
+    conv.fwd(big.ptr(), small.ptr(), n, K.epilogue(mask_mode=K.MASK_LRELU, leak=0.2, mask_src=mask.ptr()))
+    ref = T.conv2d(x.astype(np.float64), Wt.astype(np.float64), s) * np.where(m > 0, 1.0, 0.2)
+    assert relerr(small.get(), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', [(2, 32, 32, 3, 104, 5, 2), (2, 16, 16, 200, 400, 5, 2), (3, 14, 10, 1, 64, 4, 2)])
+def test_deconv_forward_bias_tanh(case, dtype):
+    """conv2d_transpose + bias + tanh in one launch (the generator's image layer: backward-data form with bias and
+    activation in the epilogue).  Covers the fused-class kernel (thin big sides, bf16) and the per-class kernels."""
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s = case           # big side h x w x cin (the deconv OUTPUT), small side cout channels
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(13)
+    big, small, conv = make_conv(K, dtype, n, h, w, cin, cout, k, s, dev)
+    y = rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cout)).astype(np.float32)
+    b = rng.standard_normal(cin).astype(np.float32)
+    if dtype == 1:
+        y, Wt = bf16_round(y), bf16_round(Wt)
+    conv.pack(torch.tensor(Wt, device=dev))
+    small.set(y)
+    conv.bwd_data(small.ptr(), big.ptr(), n, K.epilogue(bias=torch.tensor(b, device=dev), act=K.ACT_TANH))
+    ref = np.tanh(T.conv2d_transpose(y.astype(np.float64), Wt.astype(np.float64), (n, h, w, cin), s) + b)
+    assert relerr(big.get(), ref) < TOL[dtype]
+    full = big.buf.float().reshape(n, h, w, big.cs).cpu().numpy()
+    assert np.all(full[..., cin:] == 0)        # channel padding stays zero
