@@ -288,14 +288,50 @@ class GanReplica(engine.GraphRunner):
             self.D.merged_wgrad(2 * self.B, self.B, rest)
 
     def g_step(self, x01):
-        """One run of [g_train_op, losses] (models/gan.py:153,172)."""
+        """One run of [g_train_op, losses] (models/gan.py:153,172).
+
+        Several replicas (iwgan with the reported d_loss): the generator's gradients need only D(g) -- the critic passes
+        on x and x_hat and the penalty's backward exist for the REPORTED d_loss -- so the gradient path runs first, its
+        bucket starts its RCCL all-reduce asynchronously, and the display-only part (3 of the step's 5 critic passes)
+        runs underneath as a second captured body.  Rows are independent in the BN-free critic: same numbers."""
         if self.display_d_loss:
             self._load_real(x01)
-        self._run('g_grads', self._g_grads)
-        self.sess.assert_finite(self.g_store, 'g_step')
-        self._scale = average_gradients(self.sess, self.g_store)      # models/gan.py:76
+        sess, store = self.sess, self.g_store
+        if sess.world_size > 1 and self.iwgan and self.display_d_loss:
+            self._run('g_grads_a', self._g_grads_critical)
+            work = sess.allreduce_async(store.grads)
+            self._run('g_grads_b', self._g_display_d_loss)
+            work.wait()
+            sess.assert_finite(store, 'g_step')
+            self._scale = 1.0 / sess.world_size
+        else:
+            self._run('g_grads', self._g_grads)
+            sess.assert_finite(store, 'g_step')
+            self._scale = average_gradients(sess, store)              # models/gan.py:76
         self._run('g_apply', self._g_apply)
         self.sess.global_step += 1
+
+    def _g_grads_critical(self):
+        """g_loss = -mean(D(g)) and its gradient w.r.t. the generator: slot 1 only."""
+        B, R = self.B, self.B * self.rows_per_image
+        self._generate()
+        scores = self._d_forward(1, 1)
+        _lib.call('tdg_mean_f32', K.ptr(scores, 4 * R), R, K.ptr(self.scal, 4 * self.S_DFAKE), K.stream())
+        self._seed(1, -1.0 / R)
+        self.D.backward(B, B, want_params=False, want_dx=True)
+        self.G.backward(0, B, want_params=True)
+
+    def _g_display_d_loss(self):
+        """The reported d_loss (models/gan.py:199-205 fetched beside g_train_op): D(x), D(x_hat), the penalty."""
+        B, R = self.B, self.B * self.rows_per_image
+        self._rescale_real()
+        self._interpolate()
+        self._d_forward(0, 1)
+        scores = self._d_forward(2, 1)
+        _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
+        self._seed(2, 1.0)
+        self.D.backward(2 * B, B, want_params=False, want_dx=True)
+        self._penalty_from_v()
 
     def _g_grads(self):
         B, R = self.B, self.B * self.rows_per_image
