@@ -92,6 +92,10 @@ SIGNATURES = {
     'tdg_adam_step_dev': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp, _vp]),
     'tdg_add_i32': (_i, [_vp, _i, _vp]),
     'tdg_rmsprop_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
+    'tdg_rmsprop_centered_step': (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _vp]),
+    'tdg_adagrad_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _vp]),
+    'tdg_adadelta_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
+    'tdg_ftrl_step': (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     'tdg_sgd_momentum_step': (_i, [_vp, _vp, _vp, _sz, _f, _f, _f, _vp]),
     'tdg_clamp': (_i, [_vp, _sz, _f, _f, _vp]),
     'tdg_check_finite': (_i, [_vp, _sz, _vp, _vp]),

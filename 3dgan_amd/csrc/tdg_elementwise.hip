@@ -1061,6 +1061,119 @@ extern "C" int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom
   return TDG_OK;
 }
 
+// RMSProp with centered=True: the running mean of g is subtracted from the second moment (mg slot starts at 0).
+__global__ void __launch_bounds__(256) rmsprop_centered_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                              float* __restrict__ mg, float* __restrict__ rms,
+                                                              float* __restrict__ mom, size_t n4, float lr, float decay,
+                                                              float mu, float eps, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 rv = reinterpret_cast<f32x4*>(rms)[i], mv = reinterpret_cast<f32x4*>(mom)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+    f32x4 av = reinterpret_cast<f32x4*>(mg)[i];
+    rv = decay * rv + (1.f - decay) * gv * gv;
+    av = decay * av + (1.f - decay) * gv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mv[e] = mu * mv[e] + lr * gv[e] / sqrtf(rv[e] - av[e] * av[e] + eps);
+      pv[e] -= mv[e];
+    }
+    reinterpret_cast<f32x4*>(rms)[i] = rv;
+    reinterpret_cast<f32x4*>(mg)[i] = av;
+    reinterpret_cast<f32x4*>(mom)[i] = mv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_rmsprop_centered_step(float* p, const float* g, float* mg, float* rms, float* mom, size_t n, float lr,
+                                         float decay, float momentum, float eps, float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && mg && rms && mom && n > 0 && (n & 3) == 0, "tdg_rmsprop_centered_step: bad argument");
+  hipLaunchKernelGGL(rmsprop_centered_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, mg, rms,
+                     mom, n / 4, lr, decay, momentum, eps, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("rmsprop_centered");
+  return TDG_OK;
+}
+
+// Adagrad: acc += g^2; p -= lr * g / sqrt(acc)   (acc slot initialised by the caller, 0.1 in TF)
+__global__ void __launch_bounds__(256) adagrad_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ acc, size_t n4, float lr, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 av = reinterpret_cast<f32x4*>(acc)[i] + gv * gv, pv = reinterpret_cast<f32x4*>(p)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pv[e] -= lr * gv[e] / sqrtf(av[e]);
+    reinterpret_cast<f32x4*>(acc)[i] = av;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_adagrad_step(float* p, const float* g, float* acc, size_t n, float lr, float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && acc && n > 0 && (n & 3) == 0, "tdg_adagrad_step: bad argument");
+  hipLaunchKernelGGL(adagrad_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, acc, n / 4, lr,
+                     grad_scale);
+  TDG_HIP_LAUNCH_CHECK("adagrad");
+  return TDG_OK;
+}
+
+// Adadelta: acc = rho*acc + (1-rho) g^2; u = sqrt(acc_u + eps) / sqrt(acc + eps) * g; acc_u = rho*acc_u + (1-rho) u^2;
+// p -= lr * u
+__global__ void __launch_bounds__(256) adadelta_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ acc, float* __restrict__ acc_u, size_t n4,
+                                                      float lr, float rho, float eps, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 av = reinterpret_cast<f32x4*>(acc)[i], uv = reinterpret_cast<f32x4*>(acc_u)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+    av = rho * av + (1.f - rho) * gv * gv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float u = sqrtf(uv[e] + eps) / sqrtf(av[e] + eps) * gv[e];
+      uv[e] = rho * uv[e] + (1.f - rho) * u * u;
+      pv[e] -= lr * u;
+    }
+    reinterpret_cast<f32x4*>(acc)[i] = av;
+    reinterpret_cast<f32x4*>(acc_u)[i] = uv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_adadelta_step(float* p, const float* g, float* acc, float* acc_update, size_t n, float lr, float rho,
+                                 float eps, float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && acc && acc_update && n > 0 && (n & 3) == 0, "tdg_adadelta_step: bad argument");
+  hipLaunchKernelGGL(adadelta_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, acc, acc_update,
+                     n / 4, lr, rho, eps, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("adadelta");
+  return TDG_OK;
+}
+
+// FTRL-proximal with lr_power = -0.5 and the l1 / l2 strengths TF defaults to zero:
+//   acc' = acc + g^2; lin += g - (sqrt(acc') - sqrt(acc)) / lr * p; quad = sqrt(acc') / lr + 2 l2;
+//   p = |lin| > l1 ? (sign(lin) l1 - lin) / quad : 0
+__global__ void __launch_bounds__(256) ftrl_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ acc, float* __restrict__ lin, size_t n4, float lr,
+                                                  float l1, float l2, float gs) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const f32x4 gv = gs * reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 av = reinterpret_cast<f32x4*>(acc)[i], lv = reinterpret_cast<f32x4*>(lin)[i], pv = reinterpret_cast<f32x4*>(p)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float an = av[e] + gv[e] * gv[e];
+      const float sn = sqrtf(an), so = sqrtf(av[e]);
+      lv[e] += gv[e] - (sn - so) / lr * pv[e];
+      const float quad = sn / lr + 2.f * l2;
+      const float sgn = lv[e] > 0.f ? 1.f : (lv[e] < 0.f ? -1.f : 0.f);
+      pv[e] = fabsf(lv[e]) > l1 ? (sgn * l1 - lv[e]) / quad : 0.f;
+      av[e] = an;
+    }
+    reinterpret_cast<f32x4*>(acc)[i] = av;
+    reinterpret_cast<f32x4*>(lin)[i] = lv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+  }
+}
+extern "C" int tdg_ftrl_step(float* p, const float* g, float* acc, float* linear, size_t n, float lr, float l1, float l2,
+                             float grad_scale, void* stream) {
+  TDG_CHECK_ARG(p && g && acc && linear && n > 0 && (n & 3) == 0 && lr > 0.f, "tdg_ftrl_step: bad argument");
+  hipLaunchKernelGGL(ftrl_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, acc, linear, n / 4,
+                     lr, l1, l2, grad_scale);
+  TDG_HIP_LAUNCH_CHECK("ftrl");
+  return TDG_OK;
+}
+
 __global__ void __launch_bounds__(256) sgdm_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc,
                                                   size_t n4, float lr, float mu, float gs) {
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {

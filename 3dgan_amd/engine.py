@@ -158,21 +158,84 @@ class Adam(Optimizer):
 
 
 class RMSProp(Optimizer):
+    """tf.train.RMSPropOptimizer (util.py:161-164), including `--centered`."""
+
     def __init__(self, store, lr, decay=0.9, momentum=0.0, eps=1e-10, centered=False):
         super().__init__(store)
-        if centered:
-            raise NotImplementedError('--centered RMSProp is out of scope (SURVEY.md K14)')
-        self.lr, self.decay, self.mu, self.eps = lr, decay, momentum, eps
+        self.lr, self.decay, self.mu, self.eps, self.centered = lr, decay, momentum, eps, bool(centered)
         self.rms, self.mom = self._slot(1.0), self._slot()        # rms slot starts at ONE in TF
+        self.mg = self._slot() if self.centered else None
 
     def step(self, grad_scale=1.0):
         self.t += 1
         s = self.store
-        _lib.call('tdg_rmsprop_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.rms), K.ptr(self.mom), s.size,
-                  self.lr, self.decay, self.mu, self.eps, grad_scale, K.stream())
+        if self.centered:
+            _lib.call('tdg_rmsprop_centered_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.mg), K.ptr(self.rms),
+                      K.ptr(self.mom), s.size, self.lr, self.decay, self.mu, self.eps, grad_scale, K.stream())
+        else:
+            _lib.call('tdg_rmsprop_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.rms), K.ptr(self.mom), s.size,
+                      self.lr, self.decay, self.mu, self.eps, grad_scale, K.stream())
 
     def state_tensors(self):
-        return {'rms': self.rms, 'mom': self.mom}
+        d = {'rms': self.rms, 'mom': self.mom}
+        if self.centered:
+            d['mg'] = self.mg
+        return d
+
+
+class Adagrad(Optimizer):
+    """tf.train.AdagradOptimizer (util.py:167-168); ProximalAdagrad with its default zero l1/l2 strengths
+    (util.py:173-174) is the same update."""
+
+    def __init__(self, store, lr, initial_accumulator_value=0.1):
+        super().__init__(store)
+        self.lr = lr
+        self.acc = self._slot(initial_accumulator_value)
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        s = self.store
+        _lib.call('tdg_adagrad_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.acc), s.size, self.lr, grad_scale,
+                  K.stream())
+
+    def state_tensors(self):
+        return {'acc': self.acc}
+
+
+class Adadelta(Optimizer):
+    """tf.train.AdadeltaOptimizer (util.py:165-166): rho 0.95, eps 1e-8."""
+
+    def __init__(self, store, lr, rho=0.95, eps=1e-8):
+        super().__init__(store)
+        self.lr, self.rho, self.eps = lr, rho, eps
+        self.acc, self.acc_update = self._slot(), self._slot()
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        s = self.store
+        _lib.call('tdg_adadelta_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.acc), K.ptr(self.acc_update), s.size,
+                  self.lr, self.rho, self.eps, grad_scale, K.stream())
+
+    def state_tensors(self):
+        return {'acc': self.acc, 'acc_update': self.acc_update}
+
+
+class Ftrl(Optimizer):
+    """tf.train.FtrlOptimizer (util.py:182-183): lr_power -0.5, accumulator 0.1, l1 = l2 = 0."""
+
+    def __init__(self, store, lr, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        super().__init__(store)
+        self.lr, self.l1, self.l2 = lr, l1, l2
+        self.acc, self.linear = self._slot(initial_accumulator_value), self._slot()
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        s = self.store
+        _lib.call('tdg_ftrl_step', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.acc), K.ptr(self.linear), s.size,
+                  self.lr, self.l1, self.l2, grad_scale, K.stream())
+
+    def state_tensors(self):
+        return {'acc': self.acc, 'linear': self.linear}
 
 
 class Momentum(Optimizer):

@@ -40,6 +40,25 @@ def add_arg_scope(func):
     return wrapper
 
 
+def _resolve_activation(act, layer_name):
+    """The reference passes arbitrary graph-building callables as `activation=` (e.g. `lambda x: hem.lrelu(x, leak=0.2)`,
+    hem/models/paper_cgan.py:233, pix2pix.py:188).  Such a callable is traced once on a probe tensor; it must reduce to
+    exactly one of the fused epilogue activations of ops/activations.py."""
+    if act is None or isinstance(act, A.Activation):
+        return act
+    if not callable(act):
+        raise TypeError('layer %s: activation %r is not callable' % (layer_name, act))
+
+    class _Probe:
+        act = None
+    probe = Sym((None,), producer=_Probe())
+    out = act(probe)
+    if out is not probe or not isinstance(probe.producer.act, A.Activation):
+        raise NotImplementedError('layer %s: activation %r does not reduce to one of relu / lrelu / tanh / sigmoid'
+                                  % (layer_name, act))
+    return probe.producer.act
+
+
 # ------------------------------------------------------------------------------ nets / scopes
 class LayerSpec:
     def __init__(self, kind, name, in_size, out_size, k=1, stride=1, use_bn=False, act=None,
@@ -47,7 +66,7 @@ class LayerSpec:
         self.kind, self.name = kind, name
         self.dropout = dropout
         self.in_size, self.out_size, self.k, self.stride = in_size, out_size, k, stride
-        self.use_bn, self.act = use_bn, act
+        self.use_bn, self.act = use_bn, _resolve_activation(act, name)
         self.in_shape, self.out_shape = in_shape, out_shape
         self.padding, self.init = padding, init
 
@@ -241,14 +260,27 @@ def conv2d(x, input_size, output_size, filter_size=3, stride=1, init='xavier', u
 def deconv2d(x, input_size, output_size, filter_size=3, stride=2, init='xavier', use_batch_norm=False,
              activation=None, reuse=False, name=None, output_shape=None, dropout=0, use_batch_renorm=False,
              use_instance_norm=False, padding='SAME'):
-    """ops/layers.py:111-148 (gen-2: hem/ops/layers.py:138-211): tf.nn.conv2d_transpose SAME, output = 2 x input."""
+    """ops/layers.py:111-148 (gen-2: hem/ops/layers.py:138-211): tf.nn.conv2d_transpose; output = 2 x input unless an
+    explicit gen-2 `output_shape` = (N, C, H, W) is given (hem/ops/layers.py:185-187, used with padding='VALID' by
+    hem/models/paper_cgan.py:237-241).  As in TF the shape must be one the forward conv maps back onto the input."""
     _reject_unsupported(name, 0, use_batch_renorm, use_instance_norm)        # dropout: recorded; the executor decides
-    if output_shape is not None or padding != 'SAME':
-        raise NotImplementedError('deconv2d %s: explicit output_shape / VALID padding are only used by the thesis models' % name)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('deconv2d %s: input has %d channels, expected %d' % (name, c, input_size))
+    if padding not in ('SAME', 'VALID'):
+        raise ValueError('deconv2d %s: padding %r' % (name, padding))
+    if output_shape is None:
+        oh, ow = h * 2, w * 2
+    else:
+        if len(output_shape) != 4 or int(output_shape[1]) != output_size:
+            raise ValueError('deconv2d %s: output_shape %r is not (N, %d, H, W)' % (name, tuple(output_shape), output_size))
+        oh, ow = int(output_shape[2]), int(output_shape[3])
+    back = (lambda n: _same(n, filter_size, stride)) if padding == 'SAME' else \
+        (lambda n: -(-(n - filter_size + 1) // stride))
+    if (back(oh), back(ow)) != (h, w):
+        raise ValueError('deconv2d %s: a %s k%d s%d conv of a %dx%d output does not give the %dx%d input'
+                         % (name, padding, filter_size, stride, oh, ow, h, w))
     spec = LayerSpec('deconv2d', name, input_size, output_size, filter_size, stride, use_batch_norm, activation,
-                     (h, w, c), (h * 2, w * 2, output_size), 'SAME', init, dropout=dropout)
+                     (h, w, c), (oh, ow, output_size), padding, init, dropout=dropout)
     current_net().add(spec, reuse)
-    return Sym((None, h * 2, w * 2, output_size), producer=spec)
+    return Sym((None, oh, ow, output_size), producer=spec)

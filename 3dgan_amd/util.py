@@ -22,7 +22,7 @@ def average_gradients(session, store):
 
 
 def init_optimizer(args, store):
-    """util.py:150-183 (adadelta/adagrad/ftrl/proximal variants are out of scope)."""
+    """util.py:150-183, every branch."""
     o = args.optimizer
     if o == 'rmsprop':
         return engine.RMSProp(store, args.lr, decay=args.decay, momentum=args.momentum, centered=args.centered)
@@ -32,9 +32,15 @@ def init_optimizer(args, store):
         return engine.Momentum(store, args.lr, args.momentum)
     if o == 'sgd':
         return engine.Momentum(store, args.lr, 0.0)
+    if o == 'adadelta':
+        return engine.Adadelta(store, args.lr)
+    if o in ('adagrad', 'padagrad'):   # ProximalAdagrad with zero l1/l2 strengths is plain Adagrad
+        return engine.Adagrad(store, args.lr)
+    if o == 'ftrl':
+        return engine.Ftrl(store, args.lr)
     if o == 'pgd':
         return None                    # the reference forgets the `return` (util.py:171-172)
-    raise NotImplementedError('optimizer %r is not available in this build' % o)
+    raise ValueError('unknown optimizer %r' % o)
 
 
 def collection_to_dict(collection):

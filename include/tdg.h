@@ -252,6 +252,20 @@ int tdg_add_i32(int32_t* x, int32_t inc, void* stream);
 /* RMSProp (rms slot initialised to 1 by the caller), optional momentum, not centered */
 int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom, size_t n, float lr,
                      float decay, float momentum, float eps, float grad_scale, void* stream);
+/* RMSProp with centered=True (util.py:161-164 `centered = args.centered`): mg slot starts at 0 */
+int tdg_rmsprop_centered_step(float* p, const float* g, float* mg, float* rms, float* mom, size_t n,
+                              float lr, float decay, float momentum, float eps, float grad_scale,
+                              void* stream);
+/* tf.train.AdagradOptimizer / ProximalAdagradOptimizer with zero regularisation (util.py:167-168,
+ * :173-174): acc slot starts at 0.1 */
+int tdg_adagrad_step(float* p, const float* g, float* acc, size_t n, float lr, float grad_scale,
+                     void* stream);
+/* tf.train.AdadeltaOptimizer (util.py:165-166): rho 0.95, eps 1e-8 by default, slots start at 0 */
+int tdg_adadelta_step(float* p, const float* g, float* acc, float* acc_update, size_t n, float lr,
+                      float rho, float eps, float grad_scale, void* stream);
+/* tf.train.FtrlOptimizer (util.py:182-183), lr_power -0.5: acc slot starts at 0.1, linear at 0 */
+int tdg_ftrl_step(float* p, const float* g, float* acc, float* linear, size_t n, float lr, float l1,
+                  float l2, float grad_scale, void* stream);
 int tdg_sgd_momentum_step(float* p, const float* g, float* acc, size_t n, float lr, float momentum,
                           float grad_scale, void* stream);
 /* p = clamp(p, lo, hi)  (models/gan.py:142-143; never executed by the reference, App. C-3) */

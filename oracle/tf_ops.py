@@ -317,6 +317,63 @@ class SGD:
             params[k] = (params[k] - self.lr * g).astype(params[k].dtype)
 
 
+class Adagrad:
+    """tf.train.AdagradOptimizer: accumulator starts at 0.1; acc += g^2; p -= lr*g/sqrt(acc).  ProximalAdagrad with
+    its default l1 = l2 = 0 reduces to the same update."""
+
+    def __init__(self, lr=1e-3, initial_accumulator_value=0.1):
+        self.lr, self.init = lr, initial_accumulator_value
+        self.acc = {}
+
+    def apply(self, params, grads):
+        for k, g in grads.items():
+            p = params[k]
+            if k not in self.acc:
+                self.acc[k] = np.full_like(p, self.init)
+            self.acc[k] = self.acc[k] + g * g
+            params[k] = (p - self.lr * g / np.sqrt(self.acc[k])).astype(p.dtype)
+
+
+class Adadelta:
+    """tf.train.AdadeltaOptimizer(lr, rho=0.95, epsilon=1e-8)."""
+
+    def __init__(self, lr=1e-3, rho=0.95, eps=1e-8):
+        self.lr, self.rho, self.eps = lr, rho, eps
+        self.acc, self.acc_u = {}, {}
+
+    def apply(self, params, grads):
+        for k, g in grads.items():
+            p = params[k]
+            if k not in self.acc:
+                self.acc[k] = np.zeros_like(p)
+                self.acc_u[k] = np.zeros_like(p)
+            self.acc[k] = self.rho * self.acc[k] + (1 - self.rho) * g * g
+            u = np.sqrt(self.acc_u[k] + self.eps) / np.sqrt(self.acc[k] + self.eps) * g
+            self.acc_u[k] = self.rho * self.acc_u[k] + (1 - self.rho) * u * u
+            params[k] = (p - self.lr * u).astype(p.dtype)
+
+
+class Ftrl:
+    """tf.train.FtrlOptimizer(lr, learning_rate_power=-0.5, initial_accumulator_value=0.1, l1=0, l2=0)."""
+
+    def __init__(self, lr=1e-3, initial_accumulator_value=0.1, l1=0.0, l2=0.0):
+        self.lr, self.init, self.l1, self.l2 = lr, initial_accumulator_value, l1, l2
+        self.acc, self.lin = {}, {}
+
+    def apply(self, params, grads):
+        for k, g in grads.items():
+            p = params[k]
+            if k not in self.acc:
+                self.acc[k] = np.full_like(p, self.init)
+                self.lin[k] = np.zeros_like(p)
+            new_acc = self.acc[k] + g * g
+            self.lin[k] = self.lin[k] + g - (np.sqrt(new_acc) - np.sqrt(self.acc[k])) / self.lr * p
+            quad = np.sqrt(new_acc) / self.lr + 2 * self.l2
+            lin = self.lin[k]
+            params[k] = np.where(np.abs(lin) > self.l1, (np.sign(lin) * self.l1 - lin) / quad, 0).astype(p.dtype)
+            self.acc[k] = new_acc
+
+
 def init_optimizer(args):
     """util.py:150-183.  'pgd' returns None in the reference (missing return, :171-172)."""
     o = args.optimizer
@@ -328,9 +385,15 @@ def init_optimizer(args):
         return Momentum(args.lr, args.momentum)
     if o == 'sgd':
         return SGD(args.lr)
+    if o == 'adadelta':
+        return Adadelta(args.lr)
+    if o in ('adagrad', 'padagrad'):
+        return Adagrad(args.lr)
+    if o == 'ftrl':
+        return Ftrl(args.lr)
     if o == 'pgd':
         return None
-    raise NotImplementedError('optimizer %r is out of scope (SURVEY.md K14)' % o)
+    raise ValueError('unknown optimizer %r' % o)
 
 
 def average_gradients(tower_grads):

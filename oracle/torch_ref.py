@@ -54,6 +54,22 @@ def batch_norm(x, beta):
     return (x - mean) * torch.rsqrt(var + BN_EPS) + beta
 
 
+def conv2d_valid(x, K, stride):
+    """tf.nn.conv2d padding='VALID' (SURVEY App. A-1): x NHWC, K HWIO, out = ceil((in - k + 1) / stride)."""
+    y = F.conv2d(x.permute(0, 3, 1, 2), K.permute(3, 2, 0, 1).contiguous(), stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+def conv2d_transpose_valid(x, K, out_hw, stride=2):
+    """tf.nn.conv2d_transpose padding='VALID' with an explicit output_shape (hem/ops/layers.py:185-193): the adjoint of
+    the VALID conv [N,H,W,Cout] -> [N,h,w,Cin]; rows/cols of the output that no window of that conv reads stay zero."""
+    H, W = out_hw
+    full = F.conv_transpose2d(x.permute(0, 3, 1, 2).contiguous(), K.permute(3, 2, 0, 1).contiguous(), stride=stride)
+    fh, fw = full.shape[2], full.shape[3]
+    assert 0 <= H - fh < stride and 0 <= W - fw < stride, 'output_shape is not consistent with the VALID geometry'
+    return F.pad(full, (0, W - fw, 0, H - fh)).permute(0, 2, 3, 1)
+
+
 def lrelu(x, leak=0.2):
     return torch.maximum(leak * x, x)
 

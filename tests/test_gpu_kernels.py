@@ -4,6 +4,7 @@ Tolerances: f32 path 2e-5 relative to the output's max magnitude (exact-f32 MFMA
 summation order differs from NumPy); bf16 path 2e-2 (inputs rounded to bf16, f32 accumulate).
 """
 import ctypes as C
+from types import SimpleNamespace
 
 import numpy as np
 import pytest
@@ -92,6 +93,55 @@ def test_conv_fwd_bwd(case, dtype):
     dw = torch.full((k, k, cin, cout), 0.5, device=dev)
     conv.bwd_filter(big.ptr(), small.ptr(), dw, n, beta=1.0)
     ref = T.conv2d_backprop_filter(x.astype(np.float64), Wt.shape, dy.astype(np.float64), s) + 0.5
+    assert relerr(dw.cpu().numpy(), ref) < TOL[dtype]
+
+
+VALID_CASES = [
+    # the gen-2 VALID-padded k5 s2 stack (hem/models/paper_cgan.py:221-224: 65 -> 31 -> 14 -> 5 -> 1) and its mirror
+    # (deconv2d with explicit output_shape, :237-241: the transpose of the same geometry; 14 -> 5 leaves big row 13 untouched)
+    (2, 65, 65, 3, 64, 5, 2),
+    (2, 31, 31, 64, 128, 5, 2),
+    (3, 14, 14, 128, 256, 5, 2),
+    (3, 5, 5, 256, 512, 5, 2),
+    (2, 9, 12, 8, 24, 3, 1),       # VALID stride 1
+    (2, 10, 7, 16, 40, 4, 2),      # k4 s2 with a remainder column that no window reads
+]
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', VALID_CASES)
+def test_conv_valid_padding_all_forms(case, dtype):
+    """padding='VALID' (out = ceil((in - k + 1) / stride), no pad) through the same three GEMM forms:
+    forward, backward-data (= conv2d_transpose VALID with an explicit output_shape) and backward-filter."""
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(sum(case))
+    oh, ow = -(-(h - k + 1) // s), -(-(w - k + 1) // s)
+    big = K.Act(n, h, w, cin, dtype, dev)
+    small = K.Act(n, oh, ow, cout, dtype, dev)
+    conv = K.Conv(big, small, k, k, s, 0, 0)
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    Wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dy = rng.standard_normal((n, oh, ow, cout)).astype(np.float32)
+    if dtype == 1:
+        x, Wt, dy = bf16_round(x), bf16_round(Wt), bf16_round(dy)
+    conv.pack(torch.tensor(Wt, device=dev))
+    big.set(x)
+    conv.fwd(big.ptr(), small.ptr(), n, K.epilogue(bias=torch.tensor(b, device=dev), act=K.ACT_RELU))
+    ref = np.maximum(T.conv2d(x.astype(np.float64), Wt.astype(np.float64), s, 'VALID') + b, 0)
+    assert ref.shape == (n, oh, ow, cout)
+    assert relerr(small.get(), ref) < TOL[dtype]
+    small.set(dy)
+    out = big.like()
+    bb = rng.standard_normal(cin).astype(np.float32)
+    conv.bwd_data(small.ptr(), out.ptr(), n, K.epilogue(bias=torch.tensor(bb, device=dev)))
+    ref = T.conv2d_backprop_input(x.shape, Wt.astype(np.float64), dy.astype(np.float64), s, 'VALID') + bb
+    assert relerr(out.get(), ref) < TOL[dtype]
+    dw = torch.zeros(k, k, cin, cout, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n)
+    ref = T.conv2d_backprop_filter(x.astype(np.float64), Wt.shape, dy.astype(np.float64), s, 'VALID')
     assert relerr(dw.cpu().numpy(), ref) < TOL[dtype]
 
 
@@ -267,6 +317,39 @@ def test_optimizers_match_tf_rules():
         opt.apply(ref, {'p': g.astype(np.float64)})
         L.call('tdg_rmsprop_step', K.ptr(p), K.ptr(torch.tensor(g, device=dev)), K.ptr(rms), K.ptr(mom), n, 1e-3, 0.9, 0.01, 1e-10, 1.0, K.stream())
     assert relerr(p.cpu().numpy(), ref['p']) < 1e-5
+
+
+@pytest.mark.parametrize('name', ['rmsprop_centered', 'adagrad', 'padagrad', 'adadelta', 'ftrl', 'sgd', 'momentum'])
+def test_optimizer_branches_match_oracle(name):
+    """util.py:150-183: every optimizer branch the CLI exposes, through util.init_optimizer on a flat parameter store,
+    against the numpy restatement in float64 over 5 steps (with a gradient scale, as the N-tower average uses)."""
+    E = pkg('engine')
+    U = pkg('util')
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    n = 4096
+    opt_name = 'rmsprop' if name == 'rmsprop_centered' else name
+    args = SimpleNamespace(optimizer=opt_name, lr=1e-2, decay=0.9, momentum=0.3, centered=name == 'rmsprop_centered',
+                           beta1=0.5, beta2=0.9)
+    store = E.ParamStore(dev)
+    store.declare('p', (n,))
+    store.allocate()
+    p0 = rng.standard_normal(n).astype(np.float32)
+    store.load({'p': p0})
+    opt = U.init_optimizer(args, store)
+    ref_opt = T.init_optimizer(args)
+    ref = {'p': p0.astype(np.float64)}
+    for _ in range(5):
+        g = rng.standard_normal(n).astype(np.float32)
+        store.grad('p').copy_(torch.tensor(g) * 2.0)
+        opt.step(grad_scale=0.5)
+        ref_opt.apply(ref, {'p': g.astype(np.float64)})
+    got = store.state_dict()['p']
+    assert np.isfinite(got).all()
+    assert relerr(got, ref['p']) < 1e-5
+    assert set(opt.state_tensors()) == {'rmsprop_centered': {'rms', 'mom', 'mg'}, 'adagrad': {'acc'}, 'padagrad': {'acc'},
+                                        'adadelta': {'acc', 'acc_update'}, 'ftrl': {'acc', 'linear'}, 'sgd': {'acc'},
+                                        'momentum': {'acc'}}[name]
 
 
 def test_rng_statistics():

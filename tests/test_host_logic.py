@@ -188,3 +188,30 @@ def test_montage_layout_and_png_roundtrip(tmp_path):
     assert np.array_equal(dec, np.rint(img * 255).astype(np.uint8))
     files = S.write_epoch(str(tmp_path), 1, {'g_loss': 1.5, 'd_loss': -0.25}, np.zeros((64, 8, 8, 3)), np.ones((64, 8, 8, 3)))
     assert len(files) == 3 and open(files[0]).read().splitlines() == ['epoch,d_loss,g_loss', '1,-0.25,1.5']
+
+
+def test_deconv2d_rejects_inconsistent_output_shape():
+    Lm = pkg('ops.layers')
+    Lm.reset_graph()
+    with Lm.variable_scope('g'):
+        x = Lm.placeholder((None, 5, 5, 8))
+        with pytest.raises(ValueError):
+            Lm.deconv2d(x, 8, 4, 5, 2, output_shape=(2, 4, 16, 16), padding='VALID', name='bad')   # 16 -> 6, not 5
+        with pytest.raises(ValueError):
+            Lm.deconv2d(x, 8, 4, 5, 2, output_shape=(2, 3, 14, 14), padding='VALID', name='bad_c')
+        y = Lm.deconv2d(x, 8, 4, 5, 2, output_shape=(2, 4, 13, 14), padding='VALID', name='ok')
+        assert y.shape[1:] == (13, 14, 4)
+
+
+def test_lambda_activation_is_traced_to_a_fused_epilogue():
+    """`activation=lambda x: hem.lrelu(x, leak=...)` (hem/models/paper_cgan.py:233) must fuse like the token itself."""
+    Lm, act, lib = pkg('ops.layers'), pkg('ops.activations'), pkg('_lib')
+    Lm.reset_graph()
+    with Lm.variable_scope('g') as net:
+        x = Lm.placeholder((None, 8, 8, 4))
+        Lm.conv2d(x, 4, 8, 3, 1, activation=lambda t: act.lrelu(t, leak=0.1), name='a')
+        Lm.conv2d(x, 4, 8, 3, 1, activation=lambda t: act.relu(t), name='b')
+        with pytest.raises(NotImplementedError):
+            Lm.conv2d(x, 4, 8, 3, 1, activation=lambda t: t, name='c')
+    a, b = net.layers[0], net.layers[1]
+    assert (a.act.code, a.act.leak) == (lib.ACT_LRELU, 0.1) and b.act.code == lib.ACT_RELU

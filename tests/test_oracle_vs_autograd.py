@@ -64,3 +64,58 @@ def test_trainers_agree_over_two_iterations():
         rb = b.train_func([torch.tensor(v) for v in xs], [torch.tensor(v) for v in zs], [torch.tensor(v) for v in als])
         assert np.allclose(ra['g_loss'], rb['g_loss'], rtol=1e-6, atol=1e-8)
         assert np.allclose(ra['d_loss'], rb['d_loss'], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize('name', ['adagrad', 'adadelta', 'rmsprop_centered', 'momentum'])
+def test_optimizer_restatements_match_torch_optim(name):
+    """The optimizer restatements (util.py:150-183 branches) against torch.optim's independent statements of the same
+    published updates, float64, 6 steps.  TF-specific initial slots (accumulator 0.1, rms 1) are written into torch's
+    state; for RMSProp torch keeps eps outside the sqrt, so eps is set to 0 on both sides."""
+    rng = np.random.default_rng(5)
+    n = 257
+    p0 = rng.standard_normal(n)
+    grads = [rng.standard_normal(n) for _ in range(6)]
+    tp = torch.tensor(p0, dtype=torch.float64, requires_grad=True)
+    if name == 'adagrad':
+        ref, opt = T.Adagrad(1e-2), torch.optim.Adagrad([tp], lr=1e-2, initial_accumulator_value=0.1, eps=0.0)
+    elif name == 'adadelta':
+        ref, opt = T.Adadelta(0.5), torch.optim.Adadelta([tp], lr=0.5, rho=0.95, eps=1e-8)
+    elif name == 'momentum':
+        ref, opt = T.Momentum(1e-2, 0.3), torch.optim.SGD([tp], lr=1e-2, momentum=0.3)
+    else:
+        ref = T.RMSProp(1e-2, 0.9, 0.3, eps=0.0, centered=True)
+        opt = torch.optim.RMSprop([tp], lr=1e-2, alpha=0.9, momentum=0.3, eps=0.0, centered=True)
+    P = {'p': p0.copy()}
+    for i, g in enumerate(grads):
+        tp.grad = torch.tensor(g)
+        if name == 'rmsprop_centered' and i == 0:
+            opt.step()                                    # materialise the state, then rewind to TF's initial slots
+            with torch.no_grad():
+                tp.copy_(torch.tensor(p0))
+            st = opt.state[tp]
+            st['square_avg'].fill_(1.0); st['grad_avg'].zero_(); st['momentum_buffer'].zero_()
+        opt.step()
+        ref.apply(P, {'p': g})
+    assert np.allclose(P['p'], tp.detach().numpy(), rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize('case', [(2, 65, 65, 3, 8, 5, 2), (2, 14, 14, 6, 10, 5, 2), (2, 10, 7, 4, 6, 4, 3), (2, 9, 12, 3, 5, 3, 1)])
+def test_valid_padding_conv_family_matches_torch(case):
+    """padding='VALID' of the numpy conv family (gen-2 stacks 65 -> 31 -> 14 -> 5 -> 1,
+    hem/models/paper_cgan.py:221-224) against torch's conv2d and its autograd, float64."""
+    n, h, w, cin, cout, k, s = case
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, h, w, cin))
+    Wt = rng.standard_normal((k, k, cin, cout))
+    y = T.conv2d(x, Wt, s, 'VALID')
+    assert y.shape[1:3] == (T.valid_out(h, k, s), T.valid_out(w, k, s))
+    tx = torch.tensor(x).permute(0, 3, 1, 2).requires_grad_(True)
+    tw = torch.tensor(Wt).permute(3, 2, 0, 1).requires_grad_(True)
+    ty = torch.nn.functional.conv2d(tx, tw, stride=s)
+    assert np.allclose(y, ty.detach().permute(0, 2, 3, 1).numpy(), atol=1e-10)
+    dy = rng.standard_normal(y.shape)
+    ty.backward(torch.tensor(dy).permute(0, 3, 1, 2))
+    dx = T.conv2d_backprop_input(x.shape, Wt, dy, s, 'VALID')
+    dw = T.conv2d_backprop_filter(x, Wt.shape, dy, s, 'VALID')
+    assert np.allclose(dx, tx.grad.permute(0, 2, 3, 1).numpy(), atol=1e-10)
+    assert np.allclose(dw, tw.grad.permute(2, 3, 1, 0).numpy(), atol=1e-10)
