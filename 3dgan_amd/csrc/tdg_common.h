@@ -85,6 +85,31 @@ __device__ __forceinline__ float apply_act(float v, int act, float leak) {
     default: return v;
   }
 }
+// Activation chosen at compile time inside an epilogue loop: a kernel dispatches ONCE on the runtime code
+// (dispatch_act) instead of walking a branch tree per accumulator element.  ACT = TDG_ACT_GENERIC keeps the runtime
+// switch (tanh / sigmoid: one layer per net).
+#define TDG_ACT_GENERIC 99
+template <int V>
+struct IntC { static constexpr int value = V; };
+template <int ACT>
+__device__ __forceinline__ float apply_act_c(float v, int act, float leak) {
+  if constexpr (ACT == TDG_ACT_NONE) return v;
+  else if constexpr (ACT == TDG_ACT_RELU) return fmaxf(v, 0.f);
+  else if constexpr (ACT == TDG_ACT_LRELU) return fmaxf(leak * v, v);
+  else return apply_act(v, act, leak);
+}
+template <class F>
+__device__ __forceinline__ void dispatch_act(int act, F&& f) {
+  if (act == TDG_ACT_LRELU) f(IntC<TDG_ACT_LRELU>{});
+  else if (act == TDG_ACT_RELU) f(IntC<TDG_ACT_RELU>{});
+  else if (act == TDG_ACT_NONE) f(IntC<TDG_ACT_NONE>{});
+  else f(IntC<TDG_ACT_GENERIC>{});
+}
+// mask_factor with the mode folded into one value: factor = m > 0 ? 1 : mask_low(mode, leak)
+__device__ __forceinline__ float mask_low(int mode, float leak) {
+  return mode == TDG_MASK_LRELU ? leak : (mode == TDG_MASK_RELU ? 0.f : 1.f);
+}
+
 // derivative factor from the mask source (post-activation for lrelu: sign is preserved;
 // pre-activation for relu-after-BN).  TF MaximumGrad: slope `leak` at x <= 0.
 __device__ __forceinline__ float mask_factor(float m, int mode, float leak) {

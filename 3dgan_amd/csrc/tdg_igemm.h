@@ -61,5 +61,6 @@ struct WgArgs {
   int nsplit, m_per_split; // m_per_split is a multiple of the step's row count
   long long slab_stride;   // elements
   int ntiles_n, ntiles_k;
+  unsigned long long* stamps;   // diagnostic build (-DTDG_STAMPS) only; null otherwise
   short tap[IG_MAX_TAPS];
 };

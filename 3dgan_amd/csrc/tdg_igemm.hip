@@ -557,6 +557,10 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   }
 
   if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
+  // the tile's bias row goes to LDS now: its load latency hides behind the K loop instead of standing at the head
+  // of the epilogue (one workgroup per CU: nothing else runs there)
+  float* sBias = reinterpret_cast<float*>(sTap + IG_MAX_TAPS);
+  if (tid < BNL) sBias[tid] = (args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
   __syncthreads();
 
   const int r16 = lane & 15, q = lane >> 4;
@@ -693,45 +697,68 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
         }
         sPix[tid] = p;
       }
+      f32x4 bvs[TN];                                           // bias pieces of the wave's columns (zeros past N / no bias)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = (wn * TN + j) * 16 + q * 4;
-        const int n = n0 + col;
-        if (j < tnw) {
-          f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-          if (bias && n < N) bv = *reinterpret_cast<const f32x4*>(bias + n);
+      for (int j = 0; j < TN; ++j) bvs[j] = *reinterpret_cast<const f32x4*>(sBias + (wn * TN + j) * 16 + q * 4);
+      // one dispatch on the activation code, then branch-free loops over the accumulators
+      dispatch_act(act, [&](auto tag) {
+        constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            f32x4 v = acc[i][j] + bv;
+        for (int j = 0; j < TN; ++j) {
+          const int col = (wn * TN + j) * 16 + q * 4;
+          if (j < tnw) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, leak);
-            *reinterpret_cast<bf16x4*>(sE + (wm * WMR + i * 16 + r16) * PE + col * 2) =
-                bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            for (int i = 0; i < TM; ++i) {
+              f32x4 v = acc[i][j] + bvs[j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e], act, leak);
+              *reinterpret_cast<bf16x4*>(sE + (wm * WMR + i * 16 + r16) * PE + col * 2) =
+                  bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            }
+          }
+        }
+      });
+      __syncthreads();
+      const float mlow = mask_low(mmode, leak);
+      // chunk c = tid + 512 * it of the tile.  The mask pieces of ALL the thread's chunks are requested before the
+      // first one is used (a load -> multiply -> store chain per chunk paid the memory latency NIT times over)
+      constexpr int NIT = (BM * CPR + 511) / 512;
+      long long pp[NIT];
+      bf16x8 mv[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int c = tid + 512 * it;
+        const int row = c / CPR, cc = c - row * CPR;
+        const int n = n0 + cc * 8;
+        long long p = c < BM * CPR ? sPix[row] : -1;
+        if (n >= N) p = -1;
+        pp[it] = p;
+        mv[it] = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+        if (mmode != TDG_MASK_NONE && p >= 0) {
+          if (n + 8 <= N) {
+            mv[it] = *reinterpret_cast<const bf16x8*>(msk + p + n);
+          } else {                                             // 4 columns left
+            const bf16x4 h = *reinterpret_cast<const bf16x4*>(msk + p + n);
+            mv[it][0] = h[0]; mv[it][1] = h[1]; mv[it][2] = h[2]; mv[it][3] = h[3];
           }
         }
       }
-      __syncthreads();
-      for (int c = tid; c < BM * CPR; c += 512) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const long long p = pp[it];
+        if (p < 0) continue;
+        const int c = tid + 512 * it;
         const int row = c / CPR, cc = c - row * CPR;
-        const long long p = sPix[row];
         const int n = n0 + cc * 8;
-        if (p < 0 || n >= N) continue;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
+        if (mmode != TDG_MASK_NONE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[it][e] > 0.f ? 1.f : mlow));
+        }
         if (n + 8 <= N) {
-          if (mmode != TDG_MASK_NONE) {
-            const bf16x8 mv = *reinterpret_cast<const bf16x8*>(msk + p + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], mmode, leak));
-          }
           *reinterpret_cast<bf16x8*>(out + p + n) = v;
-        } else {                                               // 4 columns left
-          bf16x4 h = {v[0], v[1], v[2], v[3]};
-          if (mmode != TDG_MASK_NONE) {
-            const bf16x4 mv = *reinterpret_cast<const bf16x4*>(msk + p + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (bf16_t)((float)h[e] * mask_factor((float)mv[e], mmode, leak));
-          }
-          *reinterpret_cast<bf16x4*>(out + p + n) = h;
+        } else {
+          *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
         }
       }
       return;
@@ -757,8 +784,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   for (int j = 0; j < TN; ++j) {
     const int n = n0 + (wn * TN + j) * 16 + q * 4;
     const bool okn = (j < tnw) && (n < N);
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (okn && bias) bv = *reinterpret_cast<const f32x4*>(bias + n);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + (wn * TN + j) * 16 + q * 4);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       if (okn && okm[i]) {
@@ -1218,20 +1244,30 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 2, 0);
     wd_mma_tile<TK, TN, 0, LOADS>(acc, fa, fg, sA, sG, wk, wn, frag, ld, nmstep, (stage ^ 1) * STAGE);
   };
+  unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, wt0 = 0, wt1 = 0, wt2 = 0, w_mma = 0, w_wait = 0, w_bar = 0;
+  TDG_STAMP(ws0);
   ld.all_pieces(m_begin, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm-issued LDS-DMA is not counted by the compiler
   __syncthreads();
+  TDG_STAMP(ws1);
   int stage = 0, mstep = m_begin;
   for (; mstep + WD_MR < m_end; mstep += WD_MR) {
+    TDG_STAMP(wt0);
     step_mma(std::true_type{}, stage, mstep + WD_MR);
+    TDG_STAMP(wt1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(wt2);
     __syncthreads();
     stage ^= 1;
+#ifdef TDG_STAMPS
+    { unsigned long long wt3; TDG_STAMP(wt3); w_mma += wt1 - wt0; w_wait += wt2 - wt1; w_bar += wt3 - wt2; }
+#endif
   }
   if (mstep < m_end) {
     step_mma(std::false_type{}, stage, 0);
     __syncthreads();
   }
+  TDG_STAMP(ws2);
 
   // ---- epilogue: lane owns filter row kk (r16) x 4 consecutive n ----------------------------------
   float* slab = args.slabs + (size_t)split * (size_t)args.slab_stride;
@@ -1257,6 +1293,16 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
       }
     }
   }
+#ifdef TDG_STAMPS
+  if (args.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(ws3);
+    if (lane == 0) {
+      unsigned long long* o = args.stamps + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 8;
+      o[0] = ws0; o[1] = ws1; o[2] = ws2; o[3] = ws3; o[4] = w_mma; o[5] = w_wait; o[6] = w_bar;
+    }
+  }
+#endif
 }
 
 // dw[i] = beta*dw[i] + sum_z slabs[z][i]   (fixed summation order: 16 z-lanes, then lane order)
@@ -1541,6 +1587,7 @@ struct ThinFwdArgs {
   int act, mask_mode;
   float leak;
   int debug;              // TDG_DEBUG_ABLATE (diagnostics): 7 = no global stores, 8 = no MFMA loop
+  unsigned long long* stamps;   // diagnostic build (-DTDG_STAMPS) only: per-wave phase boundaries; null otherwise
   FastDiv fd_ow, fd_c, fd_pw;
 };
 
@@ -1555,6 +1602,8 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   const int img = tile_m / a.tiles_per_image, rt = tile_m - img * a.tiles_per_image;
   const int oy0 = rt * a.TH, n0 = tile_n * 208;
   const int npix = min(a.TH, a.OH - oy0) * a.OW;
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
+  TDG_STAMP(ts0);
 
   // ---- stage by LDS-DMA (every load in flight at once; as load / store batches the staging was latency-bound):
   // filter tile = straight copy in 16-byte chunks; patch = 4-byte pieces (two channels), out-of-image pieces and
@@ -1586,8 +1635,21 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
     }
   }
   __syncthreads();
+  TDG_STAMP(ts1);
 
   const int wm = wave >> 1, wn = wave & 1;
+  // the wave's bias pieces, loaded now so that their latency hides behind the MFMA loop (N % 4 == 0: plan_fwd_thin)
+  f32x4 bvs[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bvs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (a.bias) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + (wn * TN + j) * 16 + q * 4;
+      const f32x4 t = *reinterpret_cast<const f32x4*>(a.bias + min(n, a.N - 4));
+      if (n < a.N) bvs[j] = t;
+    }
+  }
   // patch element offset of each of this lane's 4 pixels (row r16 of row-fragment i)
   int pbase[TM];
   const int zero_off = a.PH * a.PW * 4;
@@ -1635,28 +1697,31 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
       for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0);
     }
   }
+  TDG_STAMP(ts2);
   __syncthreads();                                        // every wave is done with sW / sP: reuse LDS as the staging tile
 
   // ---- epilogue: bias + activation into an LDS tile, then whole 16-byte chunks of pixel rows to HBM ----------------
   constexpr int PE = 208 * 2 + 16, CPR = 208 * 2 / 16;
   char* sE = smem;
+  dispatch_act(a.act, [&](auto tag) {
+    constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = (wn * TN + j) * 16 + q * 4;
-    if (col >= 208) continue;
-    const int n = n0 + col;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (a.bias && n < a.N) bv = *reinterpret_cast<const f32x4*>(a.bias + n);
+    for (int j = 0; j < TN; ++j) {
+      const int col = (wn * TN + j) * 16 + q * 4;
+      if (col >= 208) continue;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      f32x4 v = acc[i][j] + bv;
+      for (int i = 0; i < TM; ++i) {
+        f32x4 v = acc[i][j] + bvs[j];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], a.act, a.leak);
-      *reinterpret_cast<bf16x4*>(sE + (wm * 64 + i * 16 + r16) * PE + col * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e], a.act, a.leak);
+        *reinterpret_cast<bf16x4*>(sE + (wm * 64 + i * 16 + r16) * PE + col * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+      }
     }
-  }
+  });
   __syncthreads();
+  TDG_STAMP(ts3);
   bf16_t* yi = a.y + ((size_t)img * a.OH + oy0) * a.OW * a.Cso;          // the tile's pixels are contiguous rows of y
+  const float mlow = mask_low(a.mask_mode, a.leak);
   for (int c = tid; c < npix * CPR; c += 256) {
     const int row = c / CPR, cc = c - row * CPR;
     const int n = n0 + cc * 8;
@@ -1666,10 +1731,23 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
     if (a.mask_mode != TDG_MASK_NONE) {
       const bf16x8 mv = *reinterpret_cast<const bf16x8*>(a.mask_src + ((size_t)img * a.OH + oy0) * a.OW * a.Cso + o);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * mask_factor((float)mv[e], a.mask_mode, a.leak));
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[e] > 0.f ? 1.f : mlow));
     }
     *reinterpret_cast<bf16x8*>(yi + o) = v;
   }
+#ifdef TDG_STAMPS
+  if (a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(ts4);
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+      o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = ts3; o[4] = ts4;
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      o[5] = hw;
+    }
+  }
+#endif
 }
 
 // filter of thin_fwd_kernel from the f32 master [kh][kw][c][k]: rows n (zero beyond N), k = tap * C + c
@@ -1731,7 +1809,8 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   a.ntiles_n = ntiles_n < 0 ? tdg_ceil_div(a.N, BN) : ntiles_n;
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
-  const size_t lds = NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int);
+  const size_t lds = NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int) + BNL * sizeof(float);   // ring, taps, bias row
+  static_assert(NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int) + BNL * sizeof(float) <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1852,6 +1931,9 @@ int launch_wgrad_dma(WgArgs& a, hipStream_t s) {
   if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d>", BN);
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
   tdg_note_kernel(name);
+#ifdef TDG_STAMPS
+  a.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
   tdg_timing_start(name, t_flops, s);
   hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN>), grid, block, lds, s, a);
   tdg_timing_stop(s);
@@ -2275,6 +2357,10 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
     f.fd_ow = make_fastdiv(d->ow);
     f.fd_c = make_fastdiv(d->c);
     f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+    f.stamps = nullptr;
+#ifdef TDG_STAMPS
+    f.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
