@@ -380,12 +380,12 @@ struct TapWalk {
 // that the K loop can place each piece between two MFMA groups instead of stalling on all of them at
 // once: with the pieces in one block the stamps showed 35-43 % of a step spent issuing them (the
 // texture path takes a 1 KiB piece every ~150 cycles with eight waves queueing) and no MFMA running.
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NW = 8>
 struct DmaLoader {
-  static constexpr int NAJ = BM / 64;
+  static constexpr int NAJ = BM / (8 * NW);                 // 8-row pieces of the gathered operand per wave
   static constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
   static constexpr int NIB = BNL / 8;
-  static constexpr int NBJ = (NIB + 7) / 8;
+  static constexpr int NBJ = (NIB + NW - 1) / NW;
   static constexpr int NP = NAJ + NBJ;
   static constexpr int VEC = 16 / (int)sizeof(T);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -482,16 +482,31 @@ __device__ __forceinline__ void dma_mma_step(f32x4 (&acc)[TM][TN], const char* p
   dma_mma_tile<T, TM, TN, 0, LOADS, ILV, LD>(acc, fa, fb, pA, pB, coff0, coff1, ld, nstage);
 }
 
-template <typename T, int BM, int BN, int NS>
-__global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args) {
+// NW = 8: waves 4 (M) x 2 (N).  NW = 4: waves 2 x 2, ONE wave per SIMD with a (BM/2) x (BN/2) tile -- the fragment
+// reads of a K step drop from 8 x (TM + TN) KB to 4 x (2 TM + TN) KB.  The stamps showed the 8-wave 192 x 208 step
+// bound by LDS bandwidth (160 KB of fragment reads + 53 KB of DMA writes per step = 1664 clocks at 128 B/clk against
+// 1344 clocks of MFMA), the second wave of each SIMD finishing its MFMAs 48 % later than the first.
+// WS = 1 (wave-specialised, NW = 8): waves 0..3 only read fragments and issue MFMAs, each on (BM/4) rows x ALL BN
+// columns (13 column tiles: no spill tile, 3 + 13 fragment KB per 39 MFMAs), waves 4..7 (one per SIMD beside a
+// compute wave) only issue the LDS-DMA pieces.  A lone compute wave per SIMD (NW = 4) lost its MFMA issue slots
+// whenever it sat in the issue of a 1 KB DMA piece; a 2 x 2 compute layout (6 x 7 tiles) does not fit 256 VGPRs.
+template <typename T, int BM, int BN, int NS, int NW = 8, int WS = 0>
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel(const IgArgs args) {
   static_assert(NS == 2 || NS == 3, "LDS ring depth");
-  static_assert(BM % 64 == 0, "4 wave rows of BM/4 = k*16 rows, 8-row DMA instructions dealt in pairs");
-  using LD = DmaLoader<T, BM, BN>;
+  static_assert(NW == 8 || NW == 4, "wave layouts");
+  static_assert(!WS || (NW == 8 && NS == 3), "the specialised form is the 8-wave 3-stage kernel");
+  constexpr int CW = WS ? NW / 2 : NW;              // waves that compute
+  constexpr int LW = WS ? NW / 2 : NW;              // waves that load
+  static_assert(BM % (8 * LW) == 0 && BM % (CW * 8) == 0, "wave rows of k*16 rows, 8-row DMA instructions dealt in pairs");
+  using LD = DmaLoader<T, BM, BN, LW>;
+  constexpr int NTHR = 64 * NW;
+  constexpr int WNW = WS ? 1 : 2;                   // wave columns
+  constexpr int WMW = CW / WNW;                     // wave rows
   constexpr int NAJ = LD::NAJ;                      // A wave-instructions per wave per step
-  constexpr int WMR = BM / 4;                       // rows per wave row
+  constexpr int WMR = BM / WMW;                     // rows per wave row
   // waves 4 (M) x 2 (N): 64 rows x 7 or 6 column tiles.  Waves w and w+4 land on the same SIMD
   // (cyclic placement), so each SIMD carries 13 column tiles in total.
-  constexpr int TM = WMR / 16, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
+  constexpr int TM = WMR / 16, TN = WS ? BN / 16 : (BN / 16 + 1) / 2, TN1 = WS ? TN : BN / 16 - TN;
   constexpr int BNL = LD::BNL;                      // B rows kept in LDS: both wave columns run TN tiles (the
                                                     // second one's last tile may spill past BN and is discarded)
   constexpr int NIB = LD::NIB;                      // B wave-instructions per step (8 rows each)
@@ -515,9 +530,13 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int par = wave & 1, wh = wave >> 1;
+  const bool is_loader = !WS || wave >= CW, is_mma = !WS || wave < CW;   // wave-uniform
+  const int lwave = WS ? (wave - CW) & (LW - 1) : wave;
+  const int par = lwave & 1, wh = lwave >> 1;
   const int rsub = lane >> 3;
   const int dbg = args.debug;                        // diagnostics: 4 / 5 / 6 = zero-record descriptor for A / B / both
+  unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;   // phase stamps (diagnostic build only)
+  TDG_STAMP(ph0);
 
   LD ld;
   ld.rA = make_rsrc(args.src, (dbg == 4 || dbg == 6) ? 0u : args.src_bytes);
@@ -546,11 +565,11 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   // ---- B rows: instruction I = 2*(wh + 4j) + par covers filter rows 8*I + rsub ---------------------------
 #pragma unroll
   for (int j = 0; j < NBJ; ++j) {
-    const int I = 2 * (wh + 4 * j) + par;
+    const int I = 2 * (wh + (LW / 2) * j) + par;
     const int n = n0 + 8 * I + rsub;
     // pieces past the tile's BN rows (the spill rows of the second wave column, whose products are discarded, and
     // the dummies that even out the piece count) load nothing: out-of-range source, destination inside the spill rows
-    static_assert(NIB % 8 == 0 || BNL > BN, "dummy pieces need spill rows to land in");
+    static_assert(NIB % LW == 0 || BNL > BN, "dummy pieces need spill rows to land in");
     const bool useful = 8 * I < BN;                    // wave-uniform
     ld.b_row[j] = (useful && n < args.N) ? ((unsigned)n * (unsigned)cl.Kp + (unsigned)(ld.lch * LD::VEC)) * (unsigned)sizeof(T) : OOB_OFFSET;
     ld.b_lds[j] = BM * IG_BKB + (I < NIB ? I : NIB - 1) * 1024;
@@ -565,7 +584,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
 
   const int r16 = lane & 15, q = lane >> 4;
   const int swl = (r16 >> 1) & 7;
-  const int wm = wave & 3, wn = wave >> 2;
+  const int wm = wave % WMW, wn = wave / WMW;
   const int tnw = wn == 0 ? TN : TN1;               // wave-uniform
   static_assert((TN * 16) % 16 == 0 && ((TN * 16) >> 1) % 8 == 0, "swizzle term must not depend on the wave's column base");
 
@@ -614,7 +633,13 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     // barrier.  Raw s_barrier: __syncthreads() would drain every outstanding LDS-DMA.
     auto wait_barrier = [&](bool more_in_flight) {
       if (more_in_flight) {
-        static_assert(LD::NP >= 3 && LD::NP <= 8, "add the immediate");
+        static_assert(LD::NP >= 3 && LD::NP <= 14, "add the immediate");
+        if constexpr (LD::NP == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        if constexpr (LD::NP == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        if constexpr (LD::NP == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+        if constexpr (LD::NP == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if constexpr (LD::NP == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
+        if constexpr (LD::NP == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
         if constexpr (LD::NP == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         if constexpr (LD::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if constexpr (LD::NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -630,15 +655,53 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
     {
       // both steps' tap lookups before the first DMA: a DS instruction behind a pending LDS-DMA gets a vmcnt(0)
       LD l1 = ld;
-      ld.prepare(0);
-      l1.prepare(1);                                 // (past the last step: every piece out of range)
-      ld.all_pieces(smem);
-      if (nsteps > 1) l1.all_pieces(smem + STAGE);
+      if (is_loader) {
+        ld.prepare(0);
+        l1.prepare(1);                               // (past the last step: every piece out of range)
+        ld.all_pieces(smem);
+        if (nsteps > 1) l1.all_pieces(smem + STAGE);
+      }
     }
     wait_barrier(nsteps > 1);
     int cur = 0, step = 0;
     unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, s_issue = 0, s_mma = 0, s_sync = 0;
-    for (; step < nsteps - 2; ++step) {
+    if constexpr (WS) {
+      // two separate loops with the same barrier sequence: the loader state is dead in the compute loop (one merged
+      // loop kept it live beside the accumulators and the fragments: spills)
+      if (is_loader) {
+        for (; step < nsteps - 2; ++step) {
+          const int nxt2 = cur == 0 ? 2 : cur - 1;     // (cur + 2) % 3
+          TDG_STAMP(t0);
+          ld.prepare(step + 2);
+          ld.all_pieces(smem + nxt2 * STAGE);
+          TDG_STAMP(t2);
+          wait_barrier(true);
+          TDG_STAMP(t3);
+          s_issue += t2 - t0; s_sync += t3 - t2;
+          cur = cur == 2 ? 0 : cur + 1;
+        }
+        for (; step < nsteps; ++step) wait_barrier(false);
+      } else {
+        for (; step < nsteps; ++step) {
+          const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
+          const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
+          TDG_STAMP(t1);
+          dma_mma_step<T, TM, TN, false, ILV, LD>(acc, pA, pB, q, swl, ld, smem);
+          TDG_STAMP(t2);
+          wait_barrier(step < nsteps - 2);
+          TDG_STAMP(t3);
+          s_mma += t2 - t1; s_sync += t3 - t2;
+          cur = cur == 2 ? 0 : cur + 1;
+        }
+      }
+#ifdef TDG_STAMPS
+      if (args.stamps && lane == 0) {
+        unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+        o[0] = s_issue; o[1] = s_mma; o[2] = s_sync; o[3] = (unsigned long long)(is_loader ? (nsteps > 2 ? nsteps - 2 : 1) : nsteps);
+      }
+#endif
+    }
+    for (; !WS && step < nsteps - 2; ++step) {
       const int nxt2 = cur == 0 ? 2 : cur - 1;         // (cur + 2) % 3
       TDG_STAMP(t0);
       ld.prepare(step + 2);                            // (worked out among the MFMAs of the previous step instead, this
@@ -653,12 +716,12 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
       cur = cur == 2 ? 0 : cur + 1;
     }
 #ifdef TDG_STAMPS
-    if (args.stamps && lane == 0) {
+    if (!WS && args.stamps && lane == 0) {
       unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
       o[0] = s_issue; o[1] = s_mma; o[2] = s_sync; o[3] = (unsigned long long)(nsteps > 2 ? nsteps - 2 : 0);
     }
 #endif
-    for (; step < nsteps; ++step) {
+    for (; !WS && step < nsteps; ++step) {
       const char* pA = smem + cur * STAGE + (wm * WMR + r16) * IG_BKB;
       const char* pB = smem + cur * STAGE + BM * IG_BKB + (wn * TN * 16 + r16) * IG_BKB;
       dma_mma_step<T, TM, TN, false, ILV, LD>(acc, pA, pB, q, swl, ld, smem);
@@ -668,6 +731,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
   }
 
   // ---- epilogue ---------------------------------------------------------------------------------------
+  TDG_STAMP(ph1);
   const int N = args.N, Cso = args.Cso;
   T* out = static_cast<T*>(args.out);
   const T* msk = static_cast<const T*>(args.mask_src);
@@ -701,7 +765,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
 #pragma unroll
       for (int j = 0; j < TN; ++j) bvs[j] = *reinterpret_cast<const f32x4*>(sBias + (wn * TN + j) * 16 + q * 4);
       // one dispatch on the activation code, then branch-free loops over the accumulators
-      dispatch_act(act, [&](auto tag) {
+      if (is_mma) dispatch_act(act, [&](auto tag) {
         constexpr int ACT = decltype(tag)::value;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -719,15 +783,16 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
         }
       });
       __syncthreads();
+      TDG_STAMP(ph2);
       const float mlow = mask_low(mmode, leak);
-      // chunk c = tid + 512 * it of the tile.  The mask pieces of ALL the thread's chunks are requested before the
+      // chunk c = tid + NTHR * it of the tile.  The mask pieces of ALL the thread's chunks are requested before the
       // first one is used (a load -> multiply -> store chain per chunk paid the memory latency NIT times over)
-      constexpr int NIT = (BM * CPR + 511) / 512;
+      constexpr int NIT = (BM * CPR + NTHR - 1) / NTHR;
       long long pp[NIT];
       bf16x8 mv[NIT];
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int c = tid + 512 * it;
+        const int c = tid + NTHR * it;
         const int row = c / CPR, cc = c - row * CPR;
         const int n = n0 + cc * 8;
         long long p = c < BM * CPR ? sPix[row] : -1;
@@ -747,7 +812,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
       for (int it = 0; it < NIT; ++it) {
         const long long p = pp[it];
         if (p < 0) continue;
-        const int c = tid + 512 * it;
+        const int c = tid + NTHR * it;
         const int row = c / CPR, cc = c - row * CPR;
         const int n = n0 + cc * 8;
         bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
@@ -761,11 +826,25 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_dma_kernel(const IgArgs args
           *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
         }
       }
+#ifdef TDG_STAMPS
+      if (args.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        TDG_STAMP(ph3);
+        if (lane == 0) {
+          unsigned long long* o = args.stamps + 262144 + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+          o[0] = ph0; o[1] = ph1; o[2] = ph2; o[3] = ph3;
+        }
+      }
+#endif
       return;
     }
   }
 
   // direct form (f32 tiles, accumulating epilogues, N not a multiple of 8): lane owns pixel r16 x 4 channels
+  // (not compiled into the wave-specialised form -- its 3 x 13 unrolled copies pass the unroll budget, the
+  //  accumulators would then live in scratch -- which the host only launches for staged epilogues)
+  if constexpr (WS) return;
+  if (!is_mma) return;
   size_t pix[TM];
   bool okm[TM];
 #pragma unroll
@@ -1803,7 +1882,7 @@ int launch_fwd_cfg(const IgArgs& a, bool veca, int grid_x, int nclasses, hipStre
 }
 
 // columns [n_begin, n_begin + ntiles_n * BN) of the problem (clipped to N)
-template <typename T, int BM, int BN, int NS>
+template <typename T, int BM, int BN, int NS, int NW = 8, int WS = 0>
 int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntiles_n = -1) {
   a.n_begin = n_begin;
   a.ntiles_n = ntiles_n < 0 ? tdg_ceil_div(a.N, BN) : ntiles_n;
@@ -1813,16 +1892,16 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   static_assert(NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int) + BNL * sizeof(float) <= 160 * 1024, "LDS budget");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_dma_kernel<T, BM, BN, NS, NW, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_dma_kernel<%s,%d,%d,%d>", sizeof(T) == 2 ? "bf16" : "f32", BM, BN, NS);
+  if (!name[0]) snprintf(name, sizeof(name), WS ? "igemm_fwd_dma_kernel<%s,%d,%d,%d,8,1>" : (NW == 8 ? "igemm_fwd_dma_kernel<%s,%d,%d,%d>" : "igemm_fwd_dma_kernel<%s,%d,%d,%d,4,0>"), sizeof(T) == 2 ? "bf16" : "f32", BM, BN, NS);
   tdg_note_kernel(name);
   const int n_end = n_begin + a.ntiles_n * BN < a.N ? n_begin + a.ntiles_n * BN : a.N;
-  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(64 * NW);
   tdg_timing_start(name, t_flops * (double)(n_end - n_begin) / (double)a.N, s);
-  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS, NW, WS>), grid, block, lds, s, a);
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
@@ -1867,6 +1946,15 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     // (a 64-row tile, two workgroups per CU, was tried for the 4-step c1 forward: no change -- with K padded 75 -> 256
     //  and N 200 -> 224 that GEMM is bound by its padded MFMA work, not by serialised prologue / epilogue phases)
     if (bm == 128) return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
+    // 192-row tile, bf16, staged epilogue: the wave-specialised form (4 compute + 4 loader waves; measured +5 % on
+    // these launches inside the training step).  TDG_DMA_NW (diagnostics): 8 = every wave loads and computes,
+    // 4 = four such waves, one per SIMD (measured: -17 %)
+    const char* nw_env = getenv("TDG_DMA_NW");
+    const int nw192 = nw_env ? atoi(nw_env) : 44;
+    if constexpr (sizeof(T) == 2)
+      if (bm == 192 && nw192 == 4) return launch_fwd_dma<T, 192, 208, 3, 4>(a, mmax, s);
+    if constexpr (sizeof(T) == 2)
+      if (bm == 192 && nw192 == 44 && !a.accumulate && ring192 != 2) return launch_fwd_dma<T, 192, 208, 3, 8, 1>(a, mmax, s);
     if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
     return launch_fwd_dma<T, 256, 208, 2>(a, mmax, s);
   }

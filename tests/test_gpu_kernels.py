@@ -148,9 +148,13 @@ def test_conv_valid_padding_all_forms(case, dtype):
 @pytest.mark.parametrize('dtype', [0, 1])
 @pytest.mark.parametrize('case', [(5, 16, 16, 200, 400, 5, 2), (9, 8, 8, 400, 200, 5, 2), (3, 9, 7, 16, 200, 4, 2)])
 def test_conv_lds_dma_variant(case, dtype, monkeypatch):
-    """The 256-row LDS-DMA tile (normally chosen for large M only) forced on small, ragged problems."""
+    """The LDS-DMA tiles (normally chosen for large M only) forced on small, ragged problems, in every wave layout."""
     for mode in ('4', '3', '0'):                 # 256-row tile, 192-row tile, register-staged kernel
         monkeypatch.setenv('TDG_DMA', mode)
+        test_conv_fwd_bwd(case, dtype)
+    monkeypatch.setenv('TDG_DMA', '3')
+    for nw in ('8', '4'):                        # the 192-row tile's other wave layouts (default: wave-specialised)
+        monkeypatch.setenv('TDG_DMA_NW', nw)
         test_conv_fwd_bwd(case, dtype)
 
 

@@ -24,13 +24,14 @@ def main():
     conv = K.Conv(big, small, k, k, s, pt, pt)
     conv.pack(torch.randn(k, k, cin, cout, device=dev) * 0.05)
     out = big.like()
-    stamps = torch.zeros(8192 * 8 * 4, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(2 * 8192 * 8 * 4, dtype=torch.int64, device=dev)
     os.environ['TDG_STAMP_PTR'] = str(stamps.data_ptr())
     fn = (lambda: conv.fwd(big.ptr(), small.ptr(), n)) if which == 'fwd' else (lambda: conv.bwd_data(small.ptr(), out.ptr(), n))
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    st = stamps.cpu().view(-1, 8, 4)
+    ph = stamps[262144:].cpu().view(-1, 8, 4).double()
+    st = stamps[:262144].cpu().view(-1, 8, 4)
     st = st[st[:, 0, 3] > 0].double()
     steps = st[:, :, 3]
     for i, name in enumerate(('issue', 'mma', 'barrier')):
@@ -38,6 +39,12 @@ def main():
         print('%-8s cycles/step (100 MHz ticks x?): mean %.1f  min %.1f  max %.1f' % (name, per.mean(), per.min(), per.max()))
     tot = (st[:, :, 0] + st[:, :, 1] + st[:, :, 2]) / steps
     print('total    %.1f ticks/step over %d blocks' % (tot.mean(), st.shape[0]))
+    ph = ph[ph[:, 0, 0] > 0]
+    if ph.shape[0]:
+        life = ph[:, :, 3] - ph[:, :, 0]
+        for nm, d in (('prologue + K loop', ph[:, :, 1] - ph[:, :, 0]), ('epilogue -> LDS', ph[:, :, 2] - ph[:, :, 1]),
+                      ('LDS -> global', ph[:, :, 3] - ph[:, :, 2])):
+            print('%-18s %5.1f %% of the workgroup lifetime (mean %.0f ticks)' % (nm, 100 * (d / life).mean(), d.mean()))
     per_wave = (st[:, :, :3] / steps[:, :, None]).mean(0)
     for wv in range(8):
         print('wave %d: issue %.1f mma %.1f barrier %.1f' % (wv, *per_wave[wv].tolist()))
