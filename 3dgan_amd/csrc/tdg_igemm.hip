@@ -537,6 +537,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
   const int dbg = args.debug;                        // diagnostics: 4 / 5 / 6 = zero-record descriptor for A / B / both
   unsigned long long ph0 = 0, ph1 = 0, ph2 = 0, ph3 = 0;   // phase stamps (diagnostic build only)
   TDG_STAMP(ph0);
+  const float bias_v = (tid < LD::BNL && args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
 
   LD ld;
   ld.rA = make_rsrc(args.src, (dbg == 4 || dbg == 6) ? 0u : args.src_bytes);
@@ -575,12 +576,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
     ld.b_lds[j] = BM * IG_BKB + (I < NIB ? I : NIB - 1) * 1024;
   }
 
-  if (tid < IG_MAX_TAPS) sTap[tid] = cl.tap[tid];
-  // the tile's bias row goes to LDS now: its load latency hides behind the K loop instead of standing at the head
-  // of the epilogue (one workgroup per CU: nothing else runs there)
+  // the tile's bias row goes to LDS: requested at the top of the kernel, written here (the row tables above covered
+  // its latency), published by the first barrier of the K loop -- instead of TN dependent loads at the head of the
+  // epilogue (one workgroup per CU: nothing else runs there)
   float* sBias = reinterpret_cast<float*>(sTap + IG_MAX_TAPS);
-  if (tid < BNL) sBias[tid] = (args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
-  __syncthreads();
+  if (tid < BNL) sBias[tid] = bias_v;
 
   const int r16 = lane & 15, q = lane >> 4;
   const int swl = (r16 >> 1) & 7;
@@ -1945,7 +1945,17 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     static const int ring192 = getenv("TDG_RING") ? atoi(getenv("TDG_RING")) : 3;     // diagnostics: 2 = 2-stage ring on the 192-row tile
     // (a 64-row tile, two workgroups per CU, was tried for the 4-step c1 forward: no change -- with K padded 75 -> 256
     //  and N 200 -> 224 that GEMM is bound by its padded MFMA work, not by serialised prologue / epilogue phases)
-    if (bm == 128) return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
+    if (bm == 128) {
+      // a grid that leaves half of the CUs idle (the generator's 2x2 / 4x4 layers at batch 512: 64-128 workgroups)
+      // takes 112-column tiles instead: twice the workgroups
+      const char* n112_env = getenv("TDG_FWD_N112");            // diagnostics: 0 = never, 1 = 128-row tiles only
+      if (per * tdg_ceil_div(mmax, 128) <= 128 && a.N > 112 && !(n112_env && atoi(n112_env) == 0)) {
+        const long long wg112 = (long long)tdg_ceil_div(a.N, 112) * a.nclasses * tdg_ceil_div(mmax, 128);
+        if (wg112 <= 128 && !(n112_env && atoi(n112_env) == 1)) return launch_fwd_dma<T, 64, 112, 3>(a, mmax, s);   // still half empty
+        return launch_fwd_dma<T, 128, 112, 3>(a, mmax, s);
+      }
+      return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
+    }
     // 192-row tile, bf16, staged epilogue: the wave-specialised form (4 compute + 4 loader waves; measured +5 % on
     // these launches inside the training step).  TDG_DMA_NW (diagnostics): 8 = every wave loads and computes,
     // 4 = four such waves, one per SIMD (measured: -17 %)

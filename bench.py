@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--no_kernel_timer', action='store_true')
     ap.add_argument('--timer_steps', type=int, default=2)
     ap.add_argument('--no_graphs', action='store_true')
+    ap.add_argument('--dump_launches', default=None, help='diagnostics: write (kernel, GFLOP, count, avg ms, TFLOP/s) per distinct launch shape to this file')
     args = ap.parse_args()
 
     rt = importlib.import_module('3dgan_amd.runtime')
@@ -182,6 +183,16 @@ def main():
                        'step_tflops': (value / args.gpus * GFLOP_PER_IMAGE_ITERATION / 1e3) if args.model == 'iwgan' else None,
                        'final_losses': status},
         }
+        if timer and args.dump_launches:
+            shapes = {}
+            for name, kms, fl in timer:
+                e = shapes.setdefault((name, round(fl / 1e9, 2)), [0, 0.0])
+                e[0] += 1
+                e[1] += kms
+            with open(args.dump_launches, 'w') as f:
+                for (name, gf), (n, tot) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    f.write('%-48s %9.2f GFLOP  x%-3d %7.4f ms  %7.1f TF  (%.3f ms per step)\n'
+                            % (name, gf, n, tot / n, gf / (tot / n) if tot else 0.0, tot / args.timer_steps))
         if timer:
             sym = {}
             for name, kms, fl in timer:
