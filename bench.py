@@ -66,7 +66,7 @@ def cpu_baseline(args):
                       '%d threads (CPU restatement, not TensorFlow)' % (n, B, dt, cores)}
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_q_pmc_fetch_write_per_kernel.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_r_pmc_fetch_write_per_kernel.json')
 
 
 def pmc_traffic(symbol):
