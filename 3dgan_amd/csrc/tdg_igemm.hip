@@ -1204,6 +1204,13 @@ struct WdLoader {
   }
 };
 
+// Diagnostic builds only (-DTDG_WG_ABLATE=n, never the product library): 1 = the filter-gradient K loop without its
+// MFMAs (fragments still read), 3 = without LDS-DMA pieces.  Measured on c3 (1024 images, 0.311 ms): 0.238 ms
+// without MFMAs, 0.229 ms without the DMA pieces -- the 168 KB of 8-byte transposing fragment reads per step are the
+// floor (~64 B/clk), the DMA issue costs a quarter on top.
+#ifndef TDG_WG_ABLATE
+#define TDG_WG_ABLATE 0
+#endif
 template <int TK, int TN, int t, bool LOADS, typename FragFn>
 __device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2][TK], bf16x8 (&fg)[2 * TN], const char* sA,
                                             const char* sG, int wk, int wn, FragFn& frag, const WdLoader& ld, int nmstep, int nstage) {
@@ -1215,9 +1222,15 @@ __device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2
       fg[t + 1] = frag(sG, ks1, (wn * TN + j1) * 16);
     }
     if constexpr (t < TK) fa[1][t] = frag(sA, 1, wk * 64 + t * 16);
+#if TDG_WG_ABLATE == 1
+    asm volatile("" ::"v"(fg[t]));
+#pragma unroll
+    for (int i = 0; i < TK; ++i) asm volatile("" ::"v"(fa[ks][i]));
+#else
 #pragma unroll
     for (int i = 0; i < TK; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[t], fa[ks][i], acc[i][j], 0, 0, 0);
-    constexpr bool has_piece = LOADS && t < 8;
+#endif
+    constexpr bool has_piece = LOADS && t < 8 && TDG_WG_ABLATE != 3;
     if constexpr (has_piece) ld.template piece<t>(nmstep, nstage);
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((t + 1 < NT ? 1 : 0) + (t < TK ? 1 : 0)), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
