@@ -203,9 +203,20 @@ class GanReplica(engine.GraphRunner):
         _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
         _lib.call('tdg_mean_f32', K.ptr(scores, 4 * R), R, K.ptr(self.scal, 4 * self.S_DFAKE), K.stream())
 
-    def _seed(self, slot, value):
-        R = self.B * self.rows_per_image
-        _lib.call('tdg_fill_f32', K.ptr(self.D.layers[-1].seed, 4 * slot * R), R, value, K.stream())
+    def _seeds(self, *values):
+        """Constant dL/d(score) seeds of slots 0..len-1 (None: a slot this pass does not read).  Every distinct
+        assignment is a prefilled buffer that the critic's seed tensor is switched to; it is built once, in the eager
+        warm-up pass of the body, so a training iteration carries no fill launches for them (17 before)."""
+        bufs = self.__dict__.setdefault('_seed_bufs', {})
+        buf = bufs.get(values)
+        if buf is None:
+            R = self.B * self.rows_per_image
+            buf = torch.zeros_like(self.D.layers[-1].seed)
+            for slot, v in enumerate(values):
+                if v is not None:
+                    buf[slot * R:(slot + 1) * R] = v
+            bufs[values] = buf
+        self.D.layers[-1].seed = buf
 
     def _penalty_from_v(self):
         """slopes = sqrt(sum over the WHOLE batch tensor) (models/gan.py:229), penalty (:230)."""
@@ -263,10 +274,9 @@ class GanReplica(engine.GraphRunner):
             self._interpolate()
         scores = self._d_forward(0, self.nslots)
         self._means(scores)
-        self._seed(0, -1.0 / R)                                       # d/d(d_real) of -mean(d_real)
-        self._seed(1, 1.0 / R)                                        # d/d(d_fake) of  mean(d_fake)
+        # seeds: d/d(d_real) of -mean(d_real), d/d(d_fake) of mean(d_fake), tf.gradients(d_interpolates, ...) (:228)
+        self._seeds(-1.0 / R, 1.0 / R, 1.0) if self.iwgan else self._seeds(-1.0 / R, 1.0 / R)
         if self.iwgan:
-            self._seed(2, 1.0)                                        # tf.gradients(d_interpolates, ...) (:228)
             # first-order backward with the conv filter gradients deferred: they are taken together with the tangent-pass
             # ones, one GEMM per layer over [D(x) rows | D(g) rows | tangent rows] (engine.SeqNet.merged_wgrad)
             self.D.backward(0, 3 * B, want_params=True, want_dx=True, param_images=(0, 2 * B), dx_images=(2 * B, B),
@@ -317,7 +327,7 @@ class GanReplica(engine.GraphRunner):
         self._generate()
         scores = self._d_forward(1, 1)
         _lib.call('tdg_mean_f32', K.ptr(scores, 4 * R), R, K.ptr(self.scal, 4 * self.S_DFAKE), K.stream())
-        self._seed(1, -1.0 / R)
+        self._seeds(None, -1.0 / R)
         self.D.backward(B, B, want_params=False, want_dx=True)
         self.G.backward(0, B, want_params=True)
 
@@ -329,7 +339,7 @@ class GanReplica(engine.GraphRunner):
         self._d_forward(0, 1)
         scores = self._d_forward(2, 1)
         _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
-        self._seed(2, 1.0)
+        self._seeds(None, None, 1.0)
         self.D.backward(2 * B, B, want_params=False, want_dx=True)
         self._penalty_from_v()
 
@@ -344,12 +354,12 @@ class GanReplica(engine.GraphRunner):
         else:
             scores = self._d_forward(1, 1)
         self._means(scores)
-        self._seed(1, -1.0 / R)                                       # d/d(d_fake) of g_loss = -mean(d_fake)
         if self.iwgan and self.display_d_loss:
-            self._seed(2, 1.0)
+            self._seeds(None, -1.0 / R, 1.0)                          # d/d(d_fake) of g_loss = -mean(d_fake); x_hat's 1
             self.D.backward(B, 2 * B, want_params=False, want_dx=True)
             self._penalty_from_v()
         else:
+            self._seeds(None, -1.0 / R)
             self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
         self.G.backward(0, B, want_params=True)                       # seed = D.dx slot 1 (aliased)
 
