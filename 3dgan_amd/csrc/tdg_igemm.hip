@@ -1968,6 +1968,12 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
         if (wg112 <= 128 && !(n112_env && atoi(n112_env) == 1)) return launch_fwd_dma<T, 64, 112, 3>(a, mmax, s);   // still half empty
         return launch_fwd_dma<T, 128, 112, 3>(a, mmax, s);
       }
+      if constexpr (sizeof(T) == 2) {
+        const char* nw_env = getenv("TDG_DMA_NW");          // diagnostics: 8 = every wave loads and computes
+        const char* ws128_env = getenv("TDG_WS128");        // diagnostics: 0 = only the 192-row tile is specialised
+        if (!a.accumulate && !(nw_env && atoi(nw_env) != 44) && !(ws128_env && atoi(ws128_env) == 0))
+          return launch_fwd_dma<T, 128, 208, 3, 8, 1>(a, mmax, s);
+      }
       return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
     }
     // 192-row tile, bf16, staged epilogue: the wave-specialised form (4 compute + 4 loader waves; measured +5 % on
