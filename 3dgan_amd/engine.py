@@ -45,7 +45,8 @@ class GraphRunner:
             return body()
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local capture mode: the RCCL watchdog thread of a multi-rank run polls events while this thread captures
+        with torch.cuda.graph(g, capture_error_mode='thread_local'):
             body()
         self._graphs[name] = g
         g.replay()
