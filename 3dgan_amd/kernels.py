@@ -227,9 +227,14 @@ class Workspace:
 
     def __init__(self, device, nbytes=8 << 20):
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self._retired = []
 
     def ensure(self, nbytes):
+        """Grow on demand.  A buffer that has been handed out may be baked into a captured hipGraph (every reduction
+        writes and re-reads its partials through the pointer it was launched with), so an outgrown buffer is retired,
+        never freed: replays of an earlier capture keep a valid block of their own."""
         if self.buf.numel() < nbytes:
+            self._retired.append(self.buf)
             self.buf = torch.empty(nbytes, dtype=torch.uint8, device=self.buf.device)
         return self.buf
 

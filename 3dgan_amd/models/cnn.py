@@ -160,7 +160,7 @@ class CnnReplica(engine.GraphRunner):
         self.E.backward(0, B, want_params=True)
 
     def losses(self):
-        s = self.scal.cpu().tolist()
+        s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
         return collection_to_dict([('tower_%d/loss/loss:0' % self.sess.rank, s[0])])
 
     def samples(self, n):

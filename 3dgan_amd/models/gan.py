@@ -224,6 +224,11 @@ class GanReplica(engine.GraphRunner):
         K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
         _lib.call('tdg_gp_scalars', K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA, K.ptr(self.scal, 4 * self.S_GP), K.stream())
 
+    def big_slice(self):
+        """[lo, hi) of the critic's flat bucket holding its largest filter and that layer's bias (adjacent variables)."""
+        big, store = self._d_big_layer, self.d_store
+        return store.index[big.wname][0], store.index[big.bname][0] + (big.spec.out_size + 3) // 4 * 4
+
     # -- steps -------------------------------------------------------------------------------------
     def d_step(self, x01):
         """One run of d_train_op (models/gan.py:152,171): d_loss gradients w.r.t. D, averaged, applied.
@@ -235,19 +240,11 @@ class GanReplica(engine.GraphRunner):
         self._load_real(x01)
         sess, store = self.sess, self.d_store
         if sess.world_size > 1 and self.iwgan:
-            big = self._d_big_layer
-            off, shape = store.index[big.wname]
-            lo, hi = off, store.index[big.bname][0] + (big.spec.out_size + 3) // 4 * 4    # [weights | bias] are adjacent
+            lo, hi = self.big_slice()
             self._run('d_grads_a', self._d_grads_a)
-            work = sess.allreduce_async(store.grads[lo:hi])
-            self._run('d_grads_b', self._d_grads_b)
-            work.wait()
-            sess.assert_finite(store, 'd_step')                       # (sums over replicas: NaN/Inf survive the exchange)
-            if lo > 0:
-                sess.allreduce_mean_scale(store.grads[:lo])
-            if hi < store.size:
-                sess.allreduce_mean_scale(store.grads[hi:])
-            self._scale = 1.0 / sess.world_size
+            self._scale = sess.allreduce_split(store.grads, lo, hi, between=lambda: self._run('d_grads_b', self._d_grads_b))
+            sess.assert_finite(store, 'd_step')                       # after EVERY slice is summed: a NaN/Inf on one
+                                                                      # replica is in every replica's bucket by now
         else:
             self._run('d_grads', self._d_grads)
             sess.assert_finite(store, 'd_step')
@@ -399,16 +396,17 @@ class GanReplica(engine.GraphRunner):
 
     def losses(self):
         """Host read-back of the device scalars (one sync): models/gan.py:193-205."""
-        s = self.scal.cpu().tolist()
+        s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
+        tower = self.sess.world_size - 1          # the dict keeps the LAST tower's tensors (util.py:187-193, App. C-11)
         if self.model == 'gan':
-            return collection_to_dict([('tower_%d/g_loss:0' % self.sess.rank, s[self.S_GAN_G]),
-                                       ('tower_%d/d_loss:0' % self.sess.rank, s[self.S_GAN_D])])
+            return collection_to_dict([('tower_%d/g_loss:0' % tower, s[self.S_GAN_G]),
+                                       ('tower_%d/d_loss:0' % tower, s[self.S_GAN_D])])
         g_loss = -s[self.S_DFAKE]
         d_loss = s[self.S_DFAKE] - s[self.S_DREAL]
         if self.iwgan:
             d_loss += GP_LAMBDA * s[self.S_GP]
-        return collection_to_dict([('tower_%d/g_loss:0' % self.sess.rank, g_loss),
-                                   ('tower_%d/d_loss:0' % self.sess.rank, d_loss)])
+        return collection_to_dict([('tower_%d/g_loss:0' % tower, g_loss),
+                                   ('tower_%d/d_loss:0' % tower, d_loss)])
 
     def train_func(self, sess=None, args=None):
         """_train_wgan / _train_iwgan helper (models/gan.py:150-155,169-173): n_disc_train D steps,

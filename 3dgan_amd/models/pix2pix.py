@@ -293,7 +293,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         """sess.run(all_losses) on a third batch (hem/models/pix2pix.py:155)."""
         self._stage(batch)
         self._run('report', self._report_body)
-        s = self.scal.cpu().tolist()
+        s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
         r = self.sess.rank
         g_total = s[self.S_GFAKE] + (L1_WEIGHT * s[self.S_L1] if self.args.add_l1 else 0.0)
         g_name = 'loss/generator/add:0' if self.args.add_l1 else 'loss/generator/g_fake:0'

@@ -194,7 +194,7 @@ class VaeReplica(engine.GraphRunner):
         self.E.backward(0, B, want_params=True)
 
     def losses(self):
-        s = self.scal.cpu().tolist()
+        s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
         r = self.sess.rank
         return collection_to_dict([('tower_%d/decoder_loss:0' % r, s[self.S_DLOSS]), ('tower_%d/latent_loss:0' % r, s[self.S_LLOSS]),
                                    ('tower_%d/total_loss:0' % r, s[self.S_DLOSS] + s[self.S_LLOSS])])

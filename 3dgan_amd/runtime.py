@@ -90,24 +90,79 @@ class Session:
             return dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
+    def allreduce_split(self, flat_grads, lo, hi, between=None):
+        """The critic's exchange (models/gan.py d_step): the slice [lo, hi) of the flat bucket -- complete before the rest
+        of the bucket is -- starts its all-reduce asynchronously, `between()` enqueues the work that finishes the rest
+        (it runs underneath the exchange), then the remaining pieces follow.  Equal to ONE all-reduce of the whole
+        bucket (tests/test_distributed_cpu.py).  Returns the 1/n the optimizer kernel applies."""
+        work = self.allreduce_async(flat_grads[lo:hi])
+        if between is not None:
+            between()
+        if work is not None:
+            work.wait()
+        if lo > 0:
+            self.allreduce_mean_scale(flat_grads[:lo])
+        if hi < flat_grads.numel():
+            self.allreduce_mean_scale(flat_grads[hi:])
+        return 1.0 / self.world_size
+
+    def report_scalars(self, scal, mean=False):
+        """The loss scalars every rank reports: those of the LAST replica (the reference's loss dict is overwritten tower
+        by tower, util.py:187-193), or their mean over replicas with the opt-in --mean_loss."""
+        if self.world_size <= 1 or not dist.is_initialized():
+            return scal
+        t = scal.clone()
+        if mean:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t /= self.world_size
+        else:
+            dist.broadcast(t, src=self.world_size - 1)
+        return t
+
     def assert_finite(self, store, what):
-        """--check_numerics (hem/util/training.py:52-53): name the offending variable."""
+        """--check_numerics (hem/util/training.py:52-53): name the offending variable.  With several replicas the flag is
+        all-reduced (MAX) first, so every rank raises together instead of one rank leaving its peers in the next
+        collective."""
         if not self.check_numerics:
             return
+        flag = self._nonfinite_flag(store)
+        if self.world_size > 1 and dist.is_initialized():
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            for name, gv in store.grad_views.items():
+                if not bool(torch.isfinite(gv).all()):
+                    raise FloatingPointError('%s: gradient of %s has NaN or Inf' % (what, name))
+            raise FloatingPointError('%s: a gradient has NaN or Inf on another replica' % what)
+
+    def _nonfinite_flag(self, store):
+        """int32[1] on the device: 1 if the flat gradient bucket holds a NaN or Inf (one fused pass, tdg_check_finite)."""
         if self._flag is None:
             self._flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._flag.zero_()
         _lib.call('tdg_check_finite', K.ptr(store.grads), store.size, K.ptr(self._flag), K.stream())
-        if int(self._flag.item()):
-            for name, gv in store.grad_views.items():
-                if not bool(torch.isfinite(gv).all()):
-                    raise FloatingPointError('%s: gradient of %s has NaN or Inf' % (what, name))
+        return self._flag
+
+    # ---- RNG stream position (checkpoint / resume) ---------------------------------------------------------------
+    def rng_state(self):
+        """Number of z / alpha / eps / dropout draws made so far (the Philox counter offset of the next draw)."""
+        return int(self._draws_dev.item())
+
+    def set_rng_state(self, draws):
+        self._draws = int(draws)
+        self._draws_dev.fill_(int(draws))
 
 
 def local_device():
-    """cuda:<LOCAL_RANK>; ranks beyond the visible devices wrap around (single-GPU rehearsals of the N > 1 path only)."""
+    """cuda:<LOCAL_RANK>.  Only the one-GPU rehearsal of the N > 1 path (TDG_DIST_BACKEND=gloo) may place several ranks
+    on one device; under RCCL a rank without a GPU of its own is an error, not a wrap-around."""
     n = torch.cuda.device_count()
-    return torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')) % max(n, 1))
+    lr = int(os.environ.get('LOCAL_RANK', '0'))
+    if lr >= max(n, 1):
+        if os.environ.get('TDG_DIST_BACKEND') == 'gloo':
+            return torch.device('cuda', lr % max(n, 1))
+        raise _lib.TdgError('LOCAL_RANK %d >= %d visible GPUs (one process per GPU; set TDG_DIST_BACKEND=gloo only to '
+                            'rehearse the multi-rank path on fewer devices)' % (lr, n))
+    return torch.device('cuda', lr)
 
 
 def init_distributed(backend=None):

@@ -26,3 +26,25 @@ def test_two_replicas_match_one(tmp_path):
     assert set(a.files) == set(b.files)
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_bench_self_launches_its_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher environment starts its own two ranks (a child torch.distributed.run)
+    and prints ONE JSON line carrying the ranks seen on the process group and the per-bucket all-reduce times."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--batch_size', '16', '--latent_size', '16', '--timer_steps', '1'],
+                       env=env, timeout=900, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['ranks_seen'] == 2 and out['scaling'] == 'weak'
+    assert out['config']['global_batch'] == 32
+    c = out['collectives']
+    assert c['ranks_seen'] == 2 and c['backend'] == 'gloo'
+    for k in ('d_big_slice', 'd_rest', 'g_bucket'):
+        assert c[k]['ms'] > 0 and c[k]['bytes'] > 0
+    assert 'roofline' in out and 'cpu_baseline' not in out
