@@ -143,14 +143,20 @@ def test_param_store_checkpoint_round_trip(tmp_path):
     opt = eng.Optimizer(s)
     opt.set_step_count(7)
     rep = SimpleNamespace(stores=lambda: [s], optimizers=lambda: {'optimizers/generator': opt})
-    sess = SimpleNamespace(global_step=12, global_epoch=2)
+    draws = [41]
+    sess = SimpleNamespace(global_step=12, global_epoch=2, rng_state=lambda: draws[0], set_rng_state=lambda n: draws.__setitem__(0, n))
     path = str(tmp_path / 'checkpoint-2.npz')
     ck.save(path, rep, sess)
+    assert os.path.exists(path) and not os.path.exists(path + '.tmp')       # written aside, renamed into place
     s.params.zero_()
-    opt.t, sess.global_step, sess.global_epoch = 0, 0, 0
+    opt.t, sess.global_step, sess.global_epoch, draws[0] = 0, 0, 0, 0
     ck.restore(path, rep, sess)
     assert torch.equal(s['generator/vars/fc1/weights'], torch.arange(15.).view(3, 5))
-    assert (opt.t, sess.global_step, sess.global_epoch) == (7, 12, 2)
+    assert (opt.t, sess.global_step, sess.global_epoch, draws[0]) == (7, 12, 2, 41)
+    # a save that dies half-way leaves the previous archive as the newest readable one
+    with open(path + '.tmp', 'wb') as f:
+        f.write(b'PK truncated')
+    ck.restore(path, rep, sess)
 
 
 def test_montage_layout_and_png_roundtrip(tmp_path):
