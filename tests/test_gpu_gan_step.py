@@ -269,3 +269,37 @@ def test_wgan_mnist_like_free_run():
     print('iteration, loss, |hip-f64|, |torch f32-f64| (relative): ' + '; '.join('%d %s %.1e %.1e' % h for h in hist))
     assert set(out) == {'g_loss', 'd_loss'}
     _check_free_run(hist, 2)
+
+
+def test_bf16_free_run_tracks_f32():
+    """The timed dtype as a training run: the headline schedule (iwgan, adam 1e-4 / 0.5 / 0.9, n_disc_train 5) free-running
+    for 10 train_func calls = 60 optimizer steps in bf16 and in f32 on the same batches, z and alpha (both on the HIP path).
+    The reported losses of the bf16 run stay within BF16_CURVE_TOL of the f32 run's (relative to max(1, |loss|))."""
+    BF16_CURVE_TOL = 3e-2
+    gan, rt = pkg('models.gan'), pkg('runtime')
+    dev = torch.device('cuda:0')
+    B, L, shape, iters = 32, 40, (32, 32, 3), 10
+    rng = np.random.default_rng(21)
+    n = 6
+    batches = [rng.uniform(0, 1, (B,) + shape).astype(np.float32) for _ in range(iters * n)]
+    zs = [rng.standard_normal((B, L)).astype(np.float32) for _ in range(iters * n)]
+    als = [rng.uniform(0, 1, (B, 1)).astype(np.float32) for _ in range(iters * n)]
+    curves = {}
+    for dtype in (0, 1):
+        args = SimpleNamespace(model='iwgan', batch_size=B, latent_size=L, image_shape=shape, n_gpus=1, optimizer='adam',
+                               lr=1e-4, beta1=0.5, beta2=0.9, decay=0.9, momentum=0.01, centered=False, n_disc_train=5,
+                               display_d_loss=True)
+        sess = rt.Session(device=dev, dtype=dtype, seed=0, rank=0, world_size=1)
+        rep = gan.GanReplica(ListSource(batches, dev), args, sess)
+        rep.load_variables({k: v.astype(np.float32) for k, v in G.init_params(G.make_cfg('iwgan', shape, L, B), 3, np.float64).items()})
+        out = []
+        for it in range(iters):
+            sl = slice(it * n, (it + 1) * n)
+            sess.inject = {'z': list(zs[sl]), 'alpha': list(als[sl])}
+            out.append(rep.train_func())
+        curves[dtype] = out
+    dev_ = [(it, k, abs(curves[1][it][k] - curves[0][it][k]) / max(1.0, abs(curves[0][it][k]))) for it in range(iters)
+            for k in ('g_loss', 'd_loss')]
+    print('bf16 vs f32 loss curves, |diff| / max(1, |loss|): ' + '; '.join('%d %s %.1e' % d for d in dev_))
+    for it, k, d in dev_:
+        assert d < BF16_CURVE_TOL, (it, k, d, curves[1][it], curves[0][it])
