@@ -1159,87 +1159,130 @@ __global__ void __launch_bounds__(256, 2) igemm_wgrad_kernel(const WgArgs args) 
 __device__ __forceinline__ int wd_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 // Loader of igemm_wgrad_dma_kernel as 8 single wave-instructions ("pieces") per wave and step: piece 2j is the
-// j-th 2-row instruction of the gathered operand, piece 2j+1 the same rows of the dense one.  The K loop issues
-// one piece behind each of the first 8 MFMA groups of a step (see DmaLoader).
+// j-th 2-row instruction of the gathered operand, piece 2j+1 the same rows of the dense one.
+//
+// Address arithmetic is kept OFF the vector ALU: the two waves of a SIMD share its vector issue with the MFMAs, and
+// the per-piece row -> (image, y, x) decomposition (two fast divisions, six integer multiplies: quarter-rate
+// v_mul_lo/hi_u32) cost ~130 VALU instructions per wave and step -- more issue time than the step's MFMAs.  Instead a
+// lane's byte offset inside a step is a CONSTANT per piece (computed once), and the step is selected by moving the
+// buffer descriptor: base += step * bytes-per-step, num_records = end - base (scalar ALU only).  Rows past the split's
+// end, padding taps and padding columns are out-of-range offsets (zero fill) as before.  The dense operand always
+// works this way (rows are contiguous); the gathered one when a step covers whole images (64 % (GH*GW) == 0: every
+// layer of the 32x32 / 64x64 GAN), FAST = true.  Otherwise (pix2pix, VAE: images larger than a step) the gathered
+// operand keeps the per-piece decomposition.
+struct WdDescs {
+  i32x4 a1, a2, g;
+};
+// A buffer window [p, p + rem) that moves by a constant per step; scalar registers only.  (Tensors are < 4 GB -- the C
+// ABI's byte counts are 32-bit -- so a non-negative rem fits num_records.)
+struct WdCursor {
+  unsigned long long p;
+  long long rem;
+  __device__ __forceinline__ void advance(long long step) { p += (unsigned long long)step; rem -= step; }
+  __device__ __forceinline__ i32x4 desc() const {
+    const unsigned r = (int)(rem >> 32) < 0 ? 0u : (unsigned)rem;
+    return i32x4{(int)(unsigned)p, (int)(unsigned)(p >> 32), (int)r, 0x00020000};
+  }
+};
+template <bool FAST>
 struct WdLoader {
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  i32x4 rA, rA2, rG;
-  unsigned lds0;                    // LDS byte address of the ring
-  int m_switch, img_switch;         // rows >= m_switch gather from the second tensor (its image 0 = image img_switch)
+  unsigned long long baseA, baseA2, baseG;   // baseA2 = src2 - img_switch images: rows >= m_switch index it like baseA
+  long long endA, endA2, endG;               // bytes from the base that rows < min(m_end, m_switch) / < m_end may touch
+  long long stepA, stepG;                    // bytes per 64-row step (FAST: whole images)
+  unsigned voA[4], voG[4];                   // per-lane byte offsets inside a step (OOB_OFFSET: padding)
+  i32x4 rA, rA2;                             // !FAST: whole-tensor descriptors
+  unsigned lds0;                             // LDS byte address of the ring
+  int m_begin, m_switch, img_switch;         // rows >= m_switch gather from the second tensor (its image 0 = image img_switch)
   FastDiv fd_ghw, fd_gw;
-  int GHW, GW, SH, SW, Cs, sigma, Gs, m_end;
-  int a_dh, a_dw, a_koff, a_kok, g_n, g_nok, hrow;
+  int GHW, GW, SH, SW, Cs, sigma, m_end;
+  int a_dh, a_dw, a_koff, a_kok, hrow;
   int Ibase;                        // b0 | b2 << 2 | b4 << 4
+  // cursors of the three operands at the split's first step / their descriptors / one step forward
+  struct Cursors {
+    WdCursor a1, a2, g;
+  };
+  __device__ __forceinline__ Cursors begin() const {
+    Cursors c;
+    c.a1.p = baseA; c.a1.rem = endA;
+    c.a2.p = baseA2; c.a2.rem = endA2;
+    c.g.p = baseG; c.g.rem = endG;
+    return c;
+  }
+  __device__ __forceinline__ WdDescs descs(const Cursors& c) const {
+    WdDescs d;
+    d.g = c.g.desc();
+    if constexpr (FAST) {
+      d.a1 = c.a1.desc();
+      d.a2 = c.a2.desc();
+    } else {
+      d.a1 = rA;
+      d.a2 = rA2;
+    }
+    return d;
+  }
+  __device__ __forceinline__ void advance(Cursors& c) const {
+    c.g.advance(stepG);
+    if constexpr (FAST) {
+      c.a1.advance(stepA);
+      c.a2.advance(stepA);
+    }
+  }
   template <int P>
-  __device__ __forceinline__ void piece(int mstep, int stage_off) const {
+  __device__ __forceinline__ void piece(const WdDescs& d, int mstep, int stage_off) const {
     constexpr int j = P >> 1;
     constexpr int SLABB = WD_MR * WD_ROWB;
     const int I = Ibase | ((j & 1) << 1) | ((j >> 1) << 3);
-    const int m = mstep + 2 * I + hrow;
-    const int okm = m < m_end;
     if constexpr ((P & 1) == 0) {
-      const unsigned mm = okm ? (unsigned)m : 0u;
-      const bool second = mstep + 2 * I >= m_switch;          // wave-uniform (m_switch is even: both rows on one side)
-      const unsigned nbg = fd_div(mm, fd_ghw);
-      const unsigned rem = mm - nbg * (unsigned)GHW;
-      const unsigned nb = second ? nbg - (unsigned)img_switch : nbg;
-      const unsigned a = fd_div(rem, fd_gw);
-      const unsigned b = rem - a * (unsigned)GW;
-      const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
-      const int ok = okm & a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
-      const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
-      const unsigned offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
-      lds_dma_b128(second ? rA2 : rA, offa, lds0 + (unsigned)(stage_off + I * 1024));
+      // wave-uniform (m_switch is even: both rows on one side); scalar, so the descriptor is picked by s_cselect
+      const bool second = __builtin_amdgcn_readfirstlane((int)(mstep + 2 * I >= m_switch)) != 0;
+      unsigned offa;
+      if constexpr (FAST) {
+        offa = voA[j];
+      } else {
+        const int m = mstep + 2 * I + hrow;
+        const int okm = m < m_end;
+        const unsigned mm = okm ? (unsigned)m : 0u;
+        const unsigned nbg = fd_div(mm, fd_ghw);
+        const unsigned rem = mm - nbg * (unsigned)GHW;
+        const unsigned nb = second ? nbg - (unsigned)img_switch : nbg;
+        const unsigned a = fd_div(rem, fd_gw);
+        const unsigned b = rem - a * (unsigned)GW;
+        const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
+        const int ok = okm & a_kok & ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+        const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
+        offa = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
+      }
+      lds_dma_b128(second ? d.a2 : d.a1, offa, lds0 + (unsigned)(stage_off + I * 1024));
     } else {
-      const unsigned offg = (okm & g_nok) ? ((unsigned)m * (unsigned)Gs + (unsigned)g_n) * 2u : OOB_OFFSET;
-      lds_dma_b128(rG, offg, lds0 + (unsigned)(stage_off + SLABB + I * 1024));
+      lds_dma_b128(d.g, voG[j], lds0 + (unsigned)(stage_off + SLABB + I * 1024));
     }
   }
   template <int P = 0>
-  __device__ __forceinline__ void all_pieces(int mstep, int stage_off) const {
+  __device__ __forceinline__ void all_pieces(const WdDescs& d, int mstep, int stage_off) const {
     if constexpr (P < 8) {
-      piece<P>(mstep, stage_off);
-      all_pieces<P + 1>(mstep, stage_off);
+      piece<P>(d, mstep, stage_off);
+      all_pieces<P + 1>(d, mstep, stage_off);
     }
   }
 };
 
 // Diagnostic builds only (-DTDG_WG_ABLATE=n, never the product library): 1 = the filter-gradient K loop without its
-// MFMAs (fragments still read), 3 = without LDS-DMA pieces.  Measured on c3 (1024 images, 0.311 ms): 0.238 ms
+// MFMAs (fragments still read), 3 = without LDS-DMA pieces, 4 = without fragment reads.  Measured on c3 (1024 images, 0.311 ms): 0.238 ms
 // without MFMAs, 0.229 ms without the DMA pieces -- the 168 KB of 8-byte transposing fragment reads per step are the
 // floor (~64 B/clk), the DMA issue costs a quarter on top.
 #ifndef TDG_WG_ABLATE
 #define TDG_WG_ABLATE 0
 #endif
-template <int TK, int TN, int t, bool LOADS, typename FragFn>
-__device__ __forceinline__ void wd_mma_tile(f32x4 (&acc)[TK][TN], bf16x8 (&fa)[2][TK], bf16x8 (&fg)[2 * TN], const char* sA,
-                                            const char* sG, int wk, int wn, FragFn& frag, const WdLoader& ld, int nmstep, int nstage) {
-  constexpr int NT = 2 * TN;
-  if constexpr (t < NT) {
-    constexpr int ks = t / TN, j = t - ks * TN;
-    if constexpr (t + 1 < NT) {
-      constexpr int ks1 = (t + 1) / TN, j1 = (t + 1) - ks1 * TN;
-      fg[t + 1] = frag(sG, ks1, (wn * TN + j1) * 16);
-    }
-    if constexpr (t < TK) fa[1][t] = frag(sA, 1, wk * 64 + t * 16);
-#if TDG_WG_ABLATE == 1
-    asm volatile("" ::"v"(fg[t]));
-#pragma unroll
-    for (int i = 0; i < TK; ++i) asm volatile("" ::"v"(fa[ks][i]));
-#else
-#pragma unroll
-    for (int i = 0; i < TK; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fg[t], fa[ks][i], acc[i][j], 0, 0, 0);
-#endif
-    constexpr bool has_piece = LOADS && t < 8 && TDG_WG_ABLATE != 3;
-    if constexpr (has_piece) ld.template piece<t>(nmstep, nstage);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((t + 1 < NT ? 1 : 0) + (t < TK ? 1 : 0)), 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
-    if constexpr (has_piece) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-    wd_mma_tile<TK, TN, t + 1, LOADS>(acc, fa, fg, sA, sG, wk, wn, frag, ld, nmstep, nstage);
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
   }
 }
 
-template <int BN>
+template <int BN, bool FAST>
 __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs args) {
   using T = bf16_t;
   constexpr int BKK = 256, VEC = 8;
@@ -1290,15 +1333,46 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
   const int g_n = n0 + lch * VEC;
   const bool g_nok = (lch * VEC < TN * 32) && (g_n < args.N);
 
-  WdLoader ld;
-  ld.rA = rA; ld.rG = rG;
-  ld.rA2 = make_rsrc_words(args.src2 ? args.src2 : args.src, args.src2 ? args.src2_bytes : args.src_bytes);
-  ld.m_switch = args.m_switch; ld.img_switch = args.img_switch;
+  WdLoader<FAST> ld;
+  {
+    const long long imgbytes = (long long)SH * SW * Cs * 2;
+    const int m_sw = m_end < args.m_switch ? m_end : args.m_switch;
+    ld.rA = rA;
+    ld.rA2 = make_rsrc_words(args.src2 ? args.src2 : args.src, args.src2 ? args.src2_bytes : args.src_bytes);
+    ld.baseA = (unsigned long long)args.src + (unsigned long long)(m_begin / GHW) * (unsigned long long)imgbytes;
+    ld.baseA2 = (unsigned long long)(args.src2 ? args.src2 : args.src) +
+                (unsigned long long)((long long)(m_begin / GHW - args.img_switch) * imgbytes);
+    ld.endA = (long long)(m_sw / GHW - m_begin / GHW) * imgbytes;
+    ld.endA2 = (long long)(m_end / GHW - m_begin / GHW) * imgbytes;
+    ld.stepA = (long long)(WD_MR / (GHW > 0 ? GHW : 1)) * imgbytes;
+    ld.baseG = (unsigned long long)args.g + (unsigned long long)m_begin * (unsigned long long)(Gs * 2);
+    ld.endG = (long long)(m_end - m_begin) * (Gs * 2);
+    ld.stepG = (long long)WD_MR * (Gs * 2);
+  }
+  ld.m_begin = m_begin; ld.m_switch = args.m_switch; ld.img_switch = args.img_switch;
   ld.lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
   ld.fd_ghw = args.fd_ghw; ld.fd_gw = args.fd_gw;
-  ld.GHW = GHW; ld.GW = GW; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.Gs = Gs; ld.m_end = m_end;
-  ld.a_dh = a_dh; ld.a_dw = a_dw; ld.a_koff = a_koff; ld.a_kok = (int)a_kok; ld.g_n = g_n; ld.g_nok = (int)g_nok; ld.hrow = hrow;
+  ld.GHW = GHW; ld.GW = GW; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.m_end = m_end;
+  ld.a_dh = a_dh; ld.a_dw = a_dw; ld.a_koff = a_koff; ld.a_kok = (int)a_kok; ld.hrow = hrow;
   ld.Ibase = b0 | (b2 << 2) | (b4 << 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int I = ld.Ibase | ((j & 1) << 1) | ((j >> 1) << 3);
+    const int ml = 2 * I + hrow;                                     // row inside a step
+    ld.voG[j] = g_nok ? (unsigned)(ml * Gs + g_n) * 2u : OOB_OFFSET;
+    if constexpr (FAST) {
+      const unsigned nb = fd_div((unsigned)ml, args.fd_ghw);
+      const unsigned rem = (unsigned)ml - nb * (unsigned)GHW;
+      const unsigned a = fd_div(rem, args.fd_gw);
+      const unsigned b = rem - a * (unsigned)GW;
+      const int ih = (int)a * sigma + a_dh, iw = (int)b * sigma + a_dw;
+      const bool ok = a_kok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
+      const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
+      ld.voA[j] = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
+    } else {
+      ld.voA[j] = 0;
+    }
+  }
 
   const int r16 = lane & 15, q = lane >> 4;
   const int wk = wave & 3, wn = wave >> 2;
@@ -1315,6 +1389,11 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto frag = [&](const char* slab, int ks, int col0) -> bf16x8 {
+#if TDG_WG_ABLATE == 4
+    bf16x8 z = {};
+    asm volatile("" : "+v"(z));
+    return z;
+#endif
     const int col = col0 + fcol;
     const int cb = (((col >> 3) ^ fsw) << 4) + ((col & 7) << 1);
     const char* p = slab + (ks * 32 + frow) * WD_ROWB + cb;
@@ -1323,41 +1402,123 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   };
 
-  auto step_mma = [&](auto loads, int stage, int nmstep) {
-    constexpr bool LOADS = decltype(loads)::value;
-    const char* sA = smem + stage * STAGE;
-    const char* sG = sA + SLAB;
-    // software-pipelined: the fragment of column tile t+1 is requested before the MFMAs of tile t
-    bf16x8 fa[2][TK];
-    bf16x8 fg[2 * TN];
-#pragma unroll
-    for (int i = 0; i < TK; ++i) fa[0][i] = frag(sA, 0, wk * 64 + i * 16);
-    fg[0] = frag(sG, 0, (wn * TN) * 16);
-    __builtin_amdgcn_sched_group_barrier(0x100, 2 * TK + 2, 0);
-    wd_mma_tile<TK, TN, 0, LOADS>(acc, fa, fg, sA, sG, wk, wn, frag, ld, nmstep, (stage ^ 1) * STAGE);
-  };
-  unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, wt0 = 0, wt1 = 0, wt2 = 0, w_mma = 0, w_wait = 0, w_bar = 0;
+  // ---- main loop -----------------------------------------------------------------------------------------------
+  // A step = 64 pixel rows = two k-slices of 32.  Fragments are double-buffered in registers by slice: while the MFMAs of
+  // slice 0 run, every fragment of slice 1 is requested (a whole slice of lookahead instead of one column tile: the
+  // transposing reads' latency is off the MFMA chain).  The step's barrier is SKEWED: it sits TS column tiles into
+  // slice 1; behind it the fragments of the NEXT step's slice 0 are requested and the remaining MFMAs of the current
+  // step (operands already in registers) cover their latency.  The LDS-DMA pieces of step s+2 are dealt one per column
+  // tile from that barrier on (the stage they overwrite was last read before it), so the `vmcnt(0)` in front of the
+  // next barrier waits for loads issued >= 6 column tiles earlier.  Rows past m_end are out-of-range sources (zero
+  // fill), so the loop needs no peeled last step: the trailing pieces and the fragments read behind the last barrier
+  // are never used.
+  unsigned long long ws0 = 0, ws1 = 0, ws2 = 0, ws3 = 0, w_mma = 0, w_wait = 0, w_bar = 0;
   TDG_STAMP(ws0);
-  ld.all_pieces(m_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm-issued LDS-DMA is not counted by the compiler
-  __syncthreads();
-  TDG_STAMP(ws1);
-  int stage = 0, mstep = m_begin;
-  for (; mstep + WD_MR < m_end; mstep += WD_MR) {
-    TDG_STAMP(wt0);
-    step_mma(std::true_type{}, stage, mstep + WD_MR);
-    TDG_STAMP(wt1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TDG_STAMP(wt2);
-    __syncthreads();
-    stage ^= 1;
-#ifdef TDG_STAMPS
-    { unsigned long long wt3; TDG_STAMP(wt3); w_mma += wt1 - wt0; w_wait += wt2 - wt1; w_bar += wt3 - wt2; }
+  auto run = [&](auto tnw_c) {
+    constexpr int TNW = decltype(tnw_c)::value;        // column tiles of this wave (208 columns: 7 | 6)
+    constexpr int TS = TNW >= 6 ? 3 : TNW / 2;         // slice-1 tiles in front of the barrier
+    constexpr int NTAIL = TNW - TS;                    // ... and behind it
+    constexpr int NPA = 8 - (NTAIL < 4 ? NTAIL : 4);   // pieces issued in part A (the rest ride on the tail tiles)
+    constexpr int PPT = (NPA + TNW - 1) / TNW;         // ... per slice-0 column tile (1 at 208 columns, 2 at 128)
+    bf16x8 FA[2][TK], FG[2][TNW];
+    const int col_g = wn * TN * 16, col_a = wk * 64;
+    auto mma_tile = [&](auto ks_c, auto t_c) {
+      constexpr int ks = decltype(ks_c)::value, t = decltype(t_c)::value;
+#if TDG_WG_ABLATE == 1
+      asm volatile("" ::"v"(FG[ks][t]));
+#pragma unroll
+      for (int i = 0; i < TK; ++i) asm volatile("" ::"v"(FA[ks][i]));
+#else
+#pragma unroll
+      for (int i = 0; i < TK; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FG[ks][t], FA[ks][i], acc[i][t], 0, 0, 0);
 #endif
-  }
-  if (mstep < m_end) {
-    step_mma(std::false_type{}, stage, 0);
+    };
+    // prologue: step 0 into stage 0, its slice-0 fragments, and the first pieces of step 1
+    WdDescs dn1;
+    typename WdLoader<FAST>::Cursors cur = ld.begin();
+    ld.all_pieces(ld.descs(cur), m_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm-issued LDS-DMA is not counted by the compiler
     __syncthreads();
+    {
+      const char* sA = smem;
+      const char* sG = sA + SLAB;
+      static_for<0, TK>([&](auto i_c) { constexpr int i = decltype(i_c)::value; FA[0][i] = frag(sA, 0, col_a + i * 16); });
+      static_for<0, TNW>([&](auto t_c) { constexpr int t = decltype(t_c)::value; FG[0][t] = frag(sG, 0, col_g + t * 16); });
+      ld.advance(cur);
+      dn1 = ld.descs(cur);
+      const WdDescs d1 = dn1;
+      static_for<0, 8 - NPA>([&](auto p_c) { ld.template piece<decltype(p_c)::value>(d1, m_begin + WD_MR, STAGE); });
+    }
+    TDG_STAMP(ws1);
+    int stage = 0;
+    for (int mstep = m_begin; mstep < m_end; mstep += WD_MR) {
+      const char* sA = smem + stage * STAGE;
+      const char* sG = sA + SLAB;
+      const int nstage = (stage ^ 1) * STAGE;
+      ld.advance(cur);
+      const WdDescs dn2 = ld.descs(cur);                 // step s+2 (dn1: step s+1)
+      // ---- part A: slice 0 (+ the reads of slice 1, + the remaining pieces of step s+1), then slice-1 tiles [0, TS)
+      static_for<0, TNW>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        FG[1][t] = frag(sG, 1, col_g + t * 16);
+        if constexpr (t < TK) FA[1][t] = frag(sA, 1, col_a + t * 16);
+        mma_tile(IntC<0>{}, t_c);
+        constexpr int p_lo = 8 - NPA + t * PPT < 8 ? 8 - NPA + t * PPT : 8;
+        constexpr int p_hi = 8 - NPA + (t + 1) * PPT < 8 ? 8 - NPA + (t + 1) * PPT : 8;
+        constexpr int np = TDG_WG_ABLATE != 3 ? p_hi - p_lo : 0;
+        static_for<p_lo, p_lo + np>([&](auto p_c) { ld.template piece<decltype(p_c)::value>(dn1, mstep + WD_MR, nstage); });
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (1 + (t < TK ? 1 : 0)), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
+        if constexpr (np > 0) __builtin_amdgcn_sched_group_barrier(0x020, np, 0);
+      });
+      static_for<0, TS>([&](auto t_c) {
+        mma_tile(IntC<1>{}, t_c);
+        __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
+      });
+      // ---- the step's barrier: every wave's pieces of step s+1 have landed, every read of this stage has returned
+      __builtin_amdgcn_sched_barrier(0);
+#ifdef TDG_STAMPS
+      unsigned long long wt1, wt2, wt3;
+      TDG_STAMP(wt1);
+#endif
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef TDG_STAMPS
+      TDG_STAMP(wt2);
+#endif
+      __syncthreads();
+#ifdef TDG_STAMPS
+      TDG_STAMP(wt3);
+      w_wait += wt2 - wt1; w_bar += wt3 - wt2;
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- part B: the rest of slice 1; underneath, the fragments of the next step's slice 0 and the first pieces of
+      // step s+2 (into the stage this step has just finished reading)
+      const char* nA = smem + nstage;
+      const char* nG = nA + SLAB;
+      static_for<0, NTAIL>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value, t = TS + u;
+        // reads: first tail tile takes what tile 0 of the next step needs (all of A, column tile 0), the others share the rest
+        constexpr int g_lo = u == 0 ? 0 : 1 + ((TNW - 1) * (u - 1)) / (NTAIL - 1 > 0 ? NTAIL - 1 : 1);
+        constexpr int g_hi = u == 0 ? 1 : (u == NTAIL - 1 ? TNW : 1 + ((TNW - 1) * u) / (NTAIL - 1 > 0 ? NTAIL - 1 : 1));
+        if constexpr (u == 0) static_for<0, TK>([&](auto i_c) { constexpr int i = decltype(i_c)::value; FA[0][i] = frag(nA, 0, col_a + i * 16); });
+        static_for<g_lo, g_hi>([&](auto g_c) { constexpr int g = decltype(g_c)::value; FG[0][g] = frag(nG, 0, col_g + g * 16); });
+        mma_tile(IntC<1>{}, IntC<t>{});
+        constexpr bool has_piece = u < 8 - NPA && TDG_WG_ABLATE != 3;
+        if constexpr (has_piece) ld.template piece<u>(dn2, mstep + 2 * WD_MR, stage * STAGE);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * ((u == 0 ? TK : 0) + (g_hi - g_lo)), 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TK, 0);
+        if constexpr (has_piece) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      });
+      stage ^= 1;
+      dn1 = dn2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the trailing (out-of-range, zero-fill) pieces
+  };
+  if constexpr (TN1 == TN) {
+    run(IntC<TN>{});
+  } else {
+    if (wn == 0) run(IntC<TN>{});
+    else run(IntC<TN1>{});
   }
   TDG_STAMP(ws2);
 
@@ -1391,7 +1552,7 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     TDG_STAMP(ws3);
     if (lane == 0) {
       unsigned long long* o = args.stamps + (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 8;
-      o[0] = ws0; o[1] = ws1; o[2] = ws2; o[3] = ws3; o[4] = w_mma; o[5] = w_wait; o[6] = w_bar;
+      o[0] = ws0; o[1] = ws1; o[2] = ws2; o[3] = ws3; o[4] = (ws2 - ws1) - w_wait - w_bar; o[5] = w_wait; o[6] = w_bar;
     }
   }
 #endif
@@ -2066,23 +2227,23 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
   return TDG_OK;
 }
 
-template <int BN>
+template <int BN, bool FAST>
 int launch_wgrad_dma(WgArgs& a, hipStream_t s) {
   const size_t lds = 4 * (size_t)WD_MR * WD_ROWB + IG_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<BN, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d>", BN);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d,%d>", BN, (int)FAST);
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
   tdg_note_kernel(name);
 #ifdef TDG_STAMPS
   a.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
   tdg_timing_start(name, t_flops, s);
-  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN, FAST>), grid, block, lds, s, a);
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad_dma");
   return TDG_OK;
@@ -2767,7 +2928,10 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
   t_flops = conv_flops(d, n_images);
-  rc = dma ? (bn == 208 ? launch_wgrad_dma<208>(a, (hipStream_t)stream) : launch_wgrad_dma<128>(a, (hipStream_t)stream))
+  // a 64-row step of whole images: the gathered operand's offsets are per-lane constants (WdLoader)
+  const bool fast = WD_MR % (d->oh * d->ow) == 0 && !getenv("TDG_WDMA_SLOWA");
+  rc = dma ? (bn == 208 ? (fast ? launch_wgrad_dma<208, true>(a, (hipStream_t)stream) : launch_wgrad_dma<208, false>(a, (hipStream_t)stream))
+                        : (fast ? launch_wgrad_dma<128, true>(a, (hipStream_t)stream) : launch_wgrad_dma<128, false>(a, (hipStream_t)stream)))
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;

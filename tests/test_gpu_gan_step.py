@@ -275,7 +275,7 @@ def test_bf16_free_run_tracks_f32():
     """The timed dtype as a training run: the headline schedule (iwgan, adam 1e-4 / 0.5 / 0.9, n_disc_train 5) free-running
     for 10 train_func calls = 60 optimizer steps in bf16 and in f32 on the same batches, z and alpha (both on the HIP path).
     The reported losses of the bf16 run stay within BF16_CURVE_TOL of the f32 run's (relative to max(1, |loss|))."""
-    BF16_CURVE_TOL = 3e-2
+    BF16_CURVE_TOL = 2e-2          # measured: <= 5.5e-3 over the 10 iterations
     gan, rt = pkg('models.gan'), pkg('runtime')
     dev = torch.device('cuda:0')
     B, L, shape, iters = 32, 40, (32, 32, 3), 10
