@@ -103,6 +103,7 @@ SIGNATURES = {
     'tdg_random_uniform_f32': (_i, [_u64, _u64, _u64, _sz, _vp, _vp]),
     'tdg_random_normal_dev': (_i, [_i, _u64, _u64, _vp, _sz, _vp, _vp]),
     'tdg_random_uniform_f32_dev': (_i, [_u64, _u64, _vp, _sz, _vp, _vp]),
+    'tdg_png_unfilter': (_i, [C.c_char_p, _i, _i, _i, _vp]),
 }
 
 _lib = None

@@ -11,6 +11,7 @@ for f in tdg_igemm tdg_elementwise; do
   hipcc $FLAGS -c $f.hip -o $f$1.o &
   pids+=($!)
 done
+g++ -O2 -std=c++17 -fPIC -Wall -c tdg_host.cpp -o tdg_host.o   # host-only helpers
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC tdg_igemm$1.o tdg_elementwise$1.o -o $OUT
+hipcc --offload-arch=gfx950 -shared -fPIC tdg_igemm$1.o tdg_elementwise$1.o tdg_host.o -o $OUT
 echo "built $OUT"

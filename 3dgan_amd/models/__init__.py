@@ -19,7 +19,7 @@ def model_funcs():
 
 
 def get_model(name):
-    """hem/models/ModelPlugin.py:4-8: plugin lookup by `name`."""
-    from .pix2pix import pix2pix
-    plugins = {pix2pix.name: pix2pix}
-    return plugins[name]
+    """hem/models/ModelPlugin.py:4-8: plugin lookup by `name` among the classes discovered in this directory whose
+    first base is named `ModelPlugin` (3dgan_amd/plugins.py)."""
+    from ..plugins import get_model as _get
+    return _get(name)

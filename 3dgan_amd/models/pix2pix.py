@@ -26,24 +26,13 @@ from ..ops.layers import conv2d, deconv2d, concat, arg_scope, variable_scope, pl
 from ..ops.activations import Activation, tanh
 from .._lib import ACT_LRELU
 from ..util import tower_scope_range, average_gradients, init_optimizer, collection_to_dict
+from .ModelPlugin import ModelPlugin
 
 L1_WEIGHT = 10.0            # l_term, hem/models/pix2pix.py:284 (the --lambda flag is ignored by the reference)
 
 
 def _lrelu(leak):
     return Activation('lrelu', ACT_LRELU, leak)
-
-
-class ModelPlugin:
-    """hem/models/ModelPlugin.py:11-24."""
-    name = None
-
-    @staticmethod
-    def arguments():
-        return {}
-
-    def train(self, sess, args, feed_dict=None):
-        raise NotImplementedError
 
 
 class pix2pix(ModelPlugin, engine.GraphRunner):

@@ -286,6 +286,12 @@ int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, const in
 int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, float* out,
                                void* stream);
 
+/* ---- input pipeline, host side (no GPU work): PNG scanline reconstruction (filter types 0-4 of the PNG
+ *      specification) after the caller has inflated the IDAT stream -- what tf.image.decode_png does for the
+ *      reference's nyuv2 / floorplan records (hem/data/nyuv2.py:152-153, data.py:15).  `filtered` holds `rows`
+ *      scanlines of 1 + row_bytes bytes, `out` receives rows * row_bytes bytes; bpp = bytes per complete pixel. */
+int tdg_png_unfilter(const unsigned char* filtered, int rows, int row_bytes, int bpp, unsigned char* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,78 +27,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-class load_args_from_file(argparse.Action):
-    """train.py:25-37: whitespace separated `key value` pairs; '--' is prefixed when missing;
-    values given on the command line win because only truthy parsed values are copied."""
-
-    def __call__(self, parser, namespace, values, option_string=None):
-        contents = [t for line in values.read().splitlines() if not line.strip().startswith('#') for t in line.split()]
-        for i in range(int(len(contents) / 2)):
-            if contents[i * 2][0:2] != '--':
-                contents[i * 2] = '--' + contents[i * 2]
-        data = parser.parse_args(contents, namespace=namespace)
-        for k, v in vars(data).items():
-            if v and k != option_string.strip('-'):
-                setattr(namespace, k, v)
+def _arguments():
+    return importlib.import_module('3dgan_amd.arguments')
 
 
 def build_parser():
-    parser = argparse.ArgumentParser(description='Autoencoder training harness.',
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser._action_groups.pop()
-    model_args = parser.add_argument_group('Model')
-    data_args = parser.add_argument_group('Data')
-    optimizer_args = parser.add_argument_group('Optimizer')
-    train_args = parser.add_argument_group('Training')
-    misc_args = parser.add_argument_group('Miscellaneous')
-    add = misc_args.add_argument
-    add('--config', type=open, action=load_args_from_file,
-        help='Read in a file containing command arguments; command line arguments overwrite it.')
-    add('--seed', type=int, help='Randomized each execution if not set.')
-    add('--n_gpus', type=int, default=1, help='Number of GPUs (one replica process per GPU).')
-    add('--profile', default=False, action='store_true', help='Accepted for compatibility (dead flag in the reference).')
-    add('--check_numerics', default=False, action='store_true', help='Fail with the variable name on NaN/Inf gradients.')
-    add('--precision', default='bf16', choices=['bf16', 'f32'],
-        help='bf16 MFMA with f32 accumulate / master weights (throughput) or exact f32 (parity).')
-    add = train_args.add_argument
-    add('--epochs', default='3', help='Max epochs, or `+n` for n more than the restored checkpoint.')
-    add('--batch_size', type=int, default=256, help='Batch size to use, per device.')
-    add('--epoch_size', type=int, default=-1, help='Iterations per epoch; default: the whole dataset.')
-    add('--examples', type=int, default=64, help='Number of examples to generate when sampling.')
-    add('--dir', type=str, default='workspace/{}'.format(uuid.uuid4()), help='Checkpoints, logs; resumes if populated.')
-    add('--n_disc_train', type=int, default=None,
-        help='Discriminator steps per generator step (default 5; 1 for --model pix2pix, its plugin default).')
-    add = optimizer_args.add_argument
-    add('--optimizer', type=lambda s: s.lower(), default='rmsprop')
-    add('--lr', type=float, default=0.001)
-    add('--loss', type=lambda s: s.lower(), default='l1', help='Parsed but unused, as in the reference.')
-    add('--momentum', type=float, default=0.01)
-    add('--decay', type=float, default=0.9)
-    add('--centered', default=False, action='store_true')
-    add('--beta1', type=float, default=0.9)
-    add('--beta2', type=float, default=0.999)
-    add = model_args.add_argument
-    add('--model', type=lambda s: s.lower(), default='fc', help='gan | wgan | iwgan | vae | cnn | pix2pix.')
-    add('--latent_size', type=int, default=200)
-    add = data_args.add_argument
-    add('--dataset', '--data', dest='dataset', type=lambda s: s.lower(), default='floorplans',
-        help='cifar | mnist | floorplans | synthetic.')
-    add('--resize', type=int, nargs=2, help='Resize input images to w x h.')
-    add('--shuffle', default=True, action='store_true')
-    add('--buffer_size', type=int, default=10000)
-    add('--grayscale', default=False, action='store_true')
-    add('--cache_dir', default=None)
-    add('--data_dir', default='data', help='Where the dataset files live.')
-    # gen-2 plugin flags of --model pix2pix (hem/models/pix2pix.py:36-78, merged by hem/util/arguments.py:153-163)
-    p2p = parser.add_argument_group('pix2pix')
-    p2p.add_argument('--skip_layers', action='store_true', default=False, help='Accepted; skips are always on in the reference.')
-    p2p.add_argument('--noise', type=str, nargs='*', choices=['input', 'latent', 'end'], default=[])
-    p2p.add_argument('--dropout', type=float, default=0)
-    p2p.add_argument('--batch_norm_disc', action='store_true', default=False)
-    p2p.add_argument('--batch_norm_gen', action='store_true', default=False)
-    p2p.add_argument('--add_l1', action='store_true', default=False)
-    p2p.add_argument('--lambda', type=float, default=10.0, help='Ignored, as in the reference (L1 weight is 10.0).')
-    return parser
+    """The general (pass-1) parser: every gen-1 flag of train.py:62-182 and every gen-2 flag of
+    hem/util/arguments.py:32-150; plugin flags are merged by parse_args (3dgan_amd/arguments.py)."""
+    return _arguments().build_parser()
+
+
+def parse_args(argv=None):
+    """gen-2 three-pass parse (hem/util/arguments.py:153-163) incl. `@file` configs; gen-1 `--config FILE` too."""
+    return _arguments().parse_args(argv, warn=lambda m: message(m))
 
 
 def resolve_defaults(args):
@@ -133,8 +74,7 @@ def latest_checkpoint(d):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
-    parser = build_parser()
-    args = parser.parse_args(argv)
+    args = parse_args(argv)
     maybe_relaunch(args, argv)
     resolve_defaults(args)
     if args.n_gpus < 1:
