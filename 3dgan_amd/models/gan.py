@@ -263,8 +263,18 @@ class GanReplica(engine.GraphRunner):
     def _d_grads(self):
         self._d_grads_a(whole=True)
 
+    def _clip_critic(self):
+        """--wgan_clip c (opt-in): clamp every critic variable to [-c, c] BEFORE the critic step -- what
+        models/gan.py:142-148 evidently intends; in the reference the clip ops never run (the `control_dependencies` block
+        wraps an already-created op), which is this build's default too."""
+        c = float(getattr(self.args, 'wgan_clip', 0.0) or 0.0)
+        if c > 0.0:
+            _lib.call('tdg_clamp', K.ptr(self.d_store.params), self.d_store.size, -c, c, K.stream())
+            self.D.repack()
+
     def _d_grads_a(self, whole=False):
         B, R = self.B, self.B * self.rows_per_image
+        self._clip_critic()
         self._rescale_real()
         self._generate()
         if self.iwgan:

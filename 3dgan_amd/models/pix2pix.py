@@ -14,15 +14,17 @@ pass the encoder's two gradient paths (next encoder layer + skip) are summed by 
 the backward-data GEMM; D(x,y) and D(x,G(x)) run as one batched pass over [x|y ; x|g]; G(x) lands directly
 in channel 3 of D's input and dL/dG(x) is read from channel 3 of D's input gradient.
 
-`--dropout` (keep probability of decoder layers 1-3, hem/models/pix2pix.py:204-208) is executed by the U-Net below.
-Not available: `--noise` (off in the reference's configs).
+`--dropout` (keep probability of decoder layers 1-3, hem/models/pix2pix.py:204-208) and `--noise input|latent|end`
+(a U(-1,1) channel concatenated to the generator input / the 1x1 bottleneck / the last decoder layer's input,
+:183-186,204-206,223-225) are executed by the U-Net below: each noise tensor is one more channel window of a zero-copy
+concat, drawn per generator pass from the device Philox stream (keys 'noise_input', 'noise_latent', 'noise_end').
 """
 import torch
 
 from .. import _lib
 from .. import kernels as K
 from .. import engine
-from ..ops.layers import conv2d, deconv2d, concat, arg_scope, variable_scope, placeholder, reset_graph
+from ..ops.layers import conv2d, deconv2d, concat, arg_scope, variable_scope, placeholder, reset_graph, random_uniform
 from ..ops.activations import Activation, tanh
 from .._lib import ACT_LRELU
 from ..util import tower_scope_range, average_gradients, init_optimizer, collection_to_dict
@@ -61,7 +63,11 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         with arg_scope([conv2d], reuse=reuse, use_batch_norm=args.batch_norm_gen, filter_size=4, stride=2, init=init,
                        activation=_lrelu(0.2)):
             with variable_scope('enocder'):
-                e1 = conv2d(x, 3, 64, name='1', use_batch_norm=False)
+                if 'input' in args.noise:                                                  # :183-186
+                    noise = random_uniform([args.batch_size, 256, 256, 1], minval=-1.0, maxval=1.0)
+                    e1 = conv2d(concat([x, noise]), 4, 64, name='1', use_batch_norm=False)
+                else:
+                    e1 = conv2d(x, 3, 64, name='1', use_batch_norm=False)
                 e2 = conv2d(e1, 64, 128, name='2')
                 e3 = conv2d(e2, 128, 256, name='3')
                 e4 = conv2d(e3, 256, 512, name='4')
@@ -72,7 +78,11 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         with arg_scope([deconv2d, conv2d], reuse=reuse, use_batch_norm=True, filter_size=4, stride=2, init=init,
                        activation=_lrelu(0.0)):
             with variable_scope('decoder'):
-                y = deconv2d(e8, 512, 512, name='1', dropout=args.dropout)
+                if 'latent' in args.noise:                                                 # :204-206
+                    noise = random_uniform([args.batch_size, 1, 1, 512], minval=-1.0, maxval=1.0)
+                    y = deconv2d(concat([e8, noise]), 1024, 512, name='1', dropout=args.dropout)
+                else:
+                    y = deconv2d(e8, 512, 512, name='1', dropout=args.dropout)
                 y = concat([y, e7])
                 y = deconv2d(y, 1024, 512, name='2', dropout=args.dropout)
                 y = concat([y, e6])
@@ -86,7 +96,11 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
                 y = concat([y, e2])
                 y = deconv2d(y, 256, 64, name='7')
                 y = concat([y, e1])
-                y = deconv2d(y, 128, 1, name='8', activation=tanh)
+                if 'end' in args.noise:                                                    # :223-225
+                    noise = random_uniform([args.batch_size, 128, 128, 1], minval=-1.0, maxval=1.0)
+                    y = deconv2d(concat([y, noise]), 129, 1, name='8', activation=tanh)
+                else:
+                    y = deconv2d(y, 128, 1, name='8', activation=tanh)
         return y
 
     @staticmethod
@@ -109,9 +123,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         from ..runtime import Session
         self.args, self.x_y = args, x_y
         self.sess = sess = sess or Session(dtype=getattr(args, 'dtype_code', K.BF16), seed=getattr(args, 'seed', 0) or 0)
-        if getattr(args, 'noise', None):
-            raise NotImplementedError('--noise is not available in this build')
-        for flag, default in (('dropout', 0), ('batch_norm_gen', False), ('batch_norm_disc', False), ('add_l1', False)):
+        for flag, default in (('noise', []), ('dropout', 0), ('batch_norm_gen', False), ('batch_norm_disc', False), ('add_l1', False)):
             if not hasattr(args, flag):
                 setattr(args, flag, default)
         B = self.B = args.batch_size
@@ -191,6 +203,8 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         for img0 in (0, B):
             _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, cs, 2.0, -0.5, self.D.x.ptr(img0), K.stream())
         _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.y_stage), rows, 1, cs, 2.0, -0.5, self.D.x.window(3, 1).ptr(0), K.stream())
+        if self.U.xn is not None:                  # --noise input: the generator reads [x | noise] from its own buffer
+            _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, self.U.xn.cs, 2.0, -0.5, self.U.xn.ptr(0), K.stream())
 
     def _load(self, batch):
         self._stage(batch)
@@ -319,15 +333,23 @@ class UNet:
         assert len(E) == 8 and len(Dc) == 8
         self.enc_bn = [l.use_bn for l in E]
         A = lambda h, w, c: K.Act(B, h, w, c, dtype, device)
+        # --noise (hem/models/pix2pix.py:183-186,204-206,223-225): read off the layer widths the builder recorded
+        self.noise_input = E[0].in_size == x_in.c + 1
+        self.noise_latent = Dc[0].in_size == 2 * E[7].out_size
+        self.noise_end = Dc[7].in_size == Dc[6].out_size + E[0].out_size + 1
+        self.xn = A(H, W, x_in.c + 1) if self.noise_input else None
+        if self.noise_input:
+            x_in = self.xn
         # spatial size of e_k
         es = [(H >> k, W >> k) for k in range(1, 9)]
         self.cat, self.gcat = {}, {}
         for i in range(2, 9):
             cd, ce = Dc[i - 2].out_size, E[8 - i].out_size
-            if Dc[i - 1].in_size != cd + ce:
-                raise ValueError('decoder layer %d expects %d input channels, skip concat provides %d' % (i, Dc[i - 1].in_size, cd + ce))
+            extra = 1 if (i == 8 and self.noise_end) else 0
+            if Dc[i - 1].in_size != cd + ce + extra:
+                raise ValueError('decoder layer %d expects %d input channels, skip concat provides %d' % (i, Dc[i - 1].in_size, cd + ce + extra))
             h, w = es[8 - i]
-            self.cat[i], self.gcat[i] = A(h, w, cd + ce), A(h, w, cd + ce)
+            self.cat[i], self.gcat[i] = A(h, w, cd + ce + extra), A(h, w, cd + ce + extra)
         self.x_in = x_in
         # encoder activations / gradients
         self.e_h, self.e_g, self.e_pre, self.e_delta = {}, {}, {}, {}
@@ -338,6 +360,9 @@ class UNet:
                 cd = Dc[7 - k].out_size
                 self.e_h[k] = self.cat[9 - k].window(cd, co)
                 self.e_g[k] = self.gcat[9 - k].window(cd, co)         # dL/d(e_k output); == delta when no batch norm
+            elif self.noise_latent:                # [e8 | noise]: e8 is the left window of decoder layer 1's input
+                self.lat, self.glat = A(h, w, 2 * co), A(h, w, 2 * co)
+                self.e_h[k], self.e_g[k] = self.lat.window(0, co), self.glat.window(0, co)
             else:
                 self.e_h[k], self.e_g[k] = A(h, w, co), A(h, w, co)
             if self.enc_bn[k - 1]:
@@ -363,7 +388,7 @@ class UNet:
             self.e_conv[k] = K.Conv(big, small, spec.k, spec.k, spec.stride, 1, 1)
         for i in range(1, 9):
             spec = Dc[i - 1]
-            small = self.e_h[8] if i == 1 else self.cat[i]
+            small = self._d_in(i)
             self.d_conv[i] = K.Conv(self.d_pre[i], small, spec.k, spec.k, spec.stride, 1, 1)
         self.d_stats = {i: torch.zeros(2 * Dc[i - 1].out_size, dtype=torch.float32, device=device) for i in range(1, 9)}
         # tf.nn.dropout(h, keep_prob=dropout) on decoder layers built with dropout > 0 (hem/models/pix2pix.py:204-208,
@@ -372,6 +397,15 @@ class UNet:
         self.d_u = {i: torch.zeros(B * self.d_pre[i].h * self.d_pre[i].w * Dc[i - 1].out_size, dtype=torch.float32, device=device)
                     for i in range(1, 9) if self.d_keep[i] > 0}
         self.e_stats = {k: torch.zeros(2 * E[k - 1].out_size, dtype=torch.float32, device=device) for k in range(1, 9)}
+        # noise channel windows and the f32 staging of their uniform draws
+        self.noise = {}
+        if self.noise_input:
+            self.noise['noise_input'] = self.xn.window(x_in.c - 1, 1)
+        if self.noise_latent:
+            self.noise['noise_latent'] = self.lat.window(E[7].out_size, E[7].out_size)
+        if self.noise_end:
+            self.noise['noise_end'] = self.cat[8].window(Dc[7].in_size - 1, 1)
+        self.noise_u = {k: torch.zeros(B * a.h * a.w * a.c, dtype=torch.float32, device=device) for k, a in self.noise.items()}
         # variables
         nb = 0
         self.e_bn_name = {}
@@ -401,10 +435,24 @@ class UNet:
             self._pack_jobs = K.make_pack_jobs(jl)
         K.pack_all(self._pack_jobs)
 
+    def _d_in(self, i):
+        """Input tensor of decoder layer i: [e8 (| noise)] for i = 1, the skip concat otherwise."""
+        if i > 1:
+            return self.cat[i]
+        return self.lat if self.noise_latent else self.e_h[8]
+
+    def draw_noise(self):
+        """tf.random_uniform(minval=-1, maxval=1) into every noise window (one draw per generator pass, as in TF)."""
+        for key, a in self.noise.items():
+            u = self.noise_u[key]
+            self.sess.random_uniform(u, u.numel(), key)
+            _lib.call('tdg_affine_cast_rows', self.dtype, K.ptr(u), self.B * a.h * a.w, a.c, a.cs, 2.0, -0.5, a.ptr(0), K.stream())
+
     # ---- forward: G(x) into g_out ---------------------------------------------------------------------------------
     def forward(self):
         B, st = self.B, self.store
         E, Dc = self.enet.layers, self.dnet.layers
+        self.draw_noise()
         for k in range(1, 9):
             spec, conv = E[k - 1], self.e_conv[k]
             src = self.x_in if k == 1 else self.e_h[k - 1]
@@ -417,7 +465,7 @@ class UNet:
                 conv.fwd(src.ptr(), self.e_h[k].ptr(), B, K.epilogue(bias=bias, act=spec.act.code, leak=spec.act.leak))
         for i in range(1, 9):
             spec, conv = Dc[i - 1], self.d_conv[i]
-            src = self.e_h[8] if i == 1 else self.cat[i]
+            src = self._d_in(i)
             conv.bwd_data(src.ptr(), self.d_pre[i].ptr(), B, K.epilogue(bias=st[self.dnet.var_name(spec, 'bias')]))
             K.bn_fwd(self.ws, self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], spec.act.code, self.d_pre[i], self.d_h[i],
                      self.d_stats[i], leak=spec.act.leak)
@@ -441,7 +489,7 @@ class UNet:
             K.bn_bwd(self.ws, self.d_g[i], self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], self.d_stats[i], spec.act.code,
                      self.d_delta[i], g(self.d_bn_name[i]), leak=spec.act.leak)
             K.bias_grad(self.ws, self.d_delta[i], spec.out_size, g(self.dnet.var_name(spec, 'bias')))
-            src = self.e_h[8] if i == 1 else self.cat[i]
+            src = self._d_in(i)
             conv.bwd_filter(self.d_delta[i].ptr(), src.ptr(), g(self.dnet.var_name(spec, 'weights')), B, 0.0)
             if i > 1:
                 conv.fwd(self.d_delta[i].ptr(), self.gcat[i].ptr(), B)            # first writer of gcat[i] (both windows)

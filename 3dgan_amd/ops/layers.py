@@ -176,6 +176,13 @@ def random_normal(shape):
     return Sym((None,) + tuple(shape[1:]), source='random_normal')
 
 
+def random_uniform(shape, minval=0.0, maxval=1.0):
+    """tf.random_uniform (models/gan.py:224; hem/models/pix2pix.py:183,204,223): drawn on-device per step, or injected."""
+    out = Sym((None,) + tuple(shape[1:]), source='random_uniform')
+    out.minval, out.maxval = float(minval), float(maxval)
+    return out
+
+
 def reshape(x, shape):
     """tf.reshape on NHWC data: a reinterpretation, free when no channel padding is involved."""
     shape = tuple(None if s in (-1, None) else int(s) for s in shape)

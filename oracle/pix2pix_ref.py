@@ -30,9 +30,24 @@ def _bn(scope, i):
     return '%s/BatchNorm/beta' % scope if i == 0 else '%s/BatchNorm_%d/beta' % (scope, i)
 
 
+def _widths(args):
+    """Layer widths with `--noise` (hem/models/pix2pix.py:183-186,204-206,223-225): one more input channel on encoder 1,
+    512 more on decoder 1, one more on decoder 8."""
+    noise = getattr(args, 'noise', None) or []
+    enc, dec = list(ENC), list(DEC)
+    if 'input' in noise:
+        enc[0] = (4, 64)
+    if 'latent' in noise:
+        dec[0] = (1024, 512)
+    if 'end' in noise:
+        dec[7] = (129, 1)
+    return enc, dec
+
+
 def param_shapes(args):
     sh = {}
     nb = 0
+    ENC, DEC = _widths(args)
     for i, (ci, co) in enumerate(ENC, start=1):
         sh['generator/enocder/vars/%d/weights' % i] = (4, 4, ci, co)
         sh['generator/enocder/vars/%d/bias' % i] = (co,)
@@ -59,11 +74,16 @@ def init_params(args, seed=0, dtype=np.float32):
             for k, s in param_shapes(args).items()}
 
 
-def generator(P, x, args, drops=None):
+def generator(P, x, args, drops=None, noise=None):
     """x: [B,256,256,3] in [-1,1] -> [B,256,256,1] (tanh).  `drops`: the uniform draws [B,h,w,512] of the dropout on
     decoder layers 1-3 (hem/models/pix2pix.py:204-208 `dropout=args.dropout`; hem/ops/layers.py:207
-    `tf.nn.dropout(h, keep_prob=dropout)` = h * floor(keep_prob + u) / keep_prob, after the activation)."""
+    `tf.nn.dropout(h, keep_prob=dropout)` = h * floor(keep_prob + u) / keep_prob, after the activation).
+    `noise`: {'input': [B,256,256,1], 'latent': [B,1,1,512], 'end': [B,128,128,1]} draws of tf.random_uniform(-1, 1)
+    for the points named in args.noise (:183-186,204-206,223-225), concatenated as trailing channels."""
+    which = getattr(args, 'noise', None) or []
     e, h, nb = [], x, 0
+    if 'input' in which:
+        h = torch.cat([h, noise['input']], dim=-1)
     for i in range(1, 9):
         h = TR.conv2d_same(h, P['generator/enocder/vars/%d/weights' % i], 2) + P['generator/enocder/vars/%d/bias' % i]
         if args.batch_norm_gen and i > 1:
@@ -72,9 +92,13 @@ def generator(P, x, args, drops=None):
         h = TR.lrelu(h, 0.2)
         e.append(h)
     y = e[7]
+    if 'latent' in which:
+        y = torch.cat([y, noise['latent']], dim=-1)
     for i in range(1, 9):
         if i > 1:
             y = torch.cat([y, e[8 - i]], dim=-1)                                   # tf.concat([y, e_k], axis=1) in NCHW
+        if i == 8 and 'end' in which:
+            y = torch.cat([y, noise['end']], dim=-1)
         y = TR.conv2d_transpose_same(y, P['generator/decoder/vars/%d/weights' % i]) + P['generator/decoder/vars/%d/bias' % i]
         y = TR.batch_norm(y, P[_bn('generator/decoder', i - 1)])
         y = torch.tanh(y) if i == 8 else torch.relu(y)

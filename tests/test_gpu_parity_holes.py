@@ -156,3 +156,30 @@ def test_resume_is_bit_identical_to_uninterrupted(tmp_path, optimizer):
     for name, o in rep.optimizers().items():
         for slot, t in o.state_tensors().items():
             assert np.array_equal(t.cpu().numpy(), full[1][name][slot]), (name, slot)
+
+
+def test_wgan_clip_opt_in_clamps_before_the_critic_step():
+    """--wgan_clip 0.01 (SURVEY App. C-3 opt-in): the critic's variables are clamped to [-c, c] before its gradients are
+    taken (oracle: the same D step from clipped variables); the default (0) leaves them alone, like the reference, whose
+    clip ops never execute."""
+    from oracle import gan_ref as G
+    c = 0.01
+    for clip in (c, 0.0):
+        args, cfg, P, batches, zs, alphas, sess, rep = build('wgan', 0, optimizer='rmsprop')
+        args.wgan_clip = clip
+        sess.inject = {'z': [zs[0]]}
+        rep.d_step(rep.x_source.next_batch())
+        Pc = {k: (np.clip(v, -c, c) if (clip and k.startswith('discriminator/')) else v) for k, v in P.items()}
+        tr = G.GanTrainer({k: v.copy() for k, v in Pc.items()}, cfg, args)
+        x = tr.rescale(batches[0].astype(np.float64))
+        _, grads, _ = G.d_loss_and_grads(Pc, x, zs[0].astype(np.float64), None, cfg)
+        got = rep.gradients()
+        for k, g in grads.items():
+            if k.endswith('/bias') and ('/c2/' in k or '/c3/' in k):
+                continue
+            assert relerr(got[k], g) < 1e-3, (clip, k)
+        w = rep.d_store['discriminator/vars/c1/weights']
+        if clip:
+            assert float(w.abs().max()) <= c + 1e-3 + 1e-7         # clamped, then moved by one rmsprop step (lr 1e-3)
+        else:
+            assert float(w.abs().max()) > 10 * c

@@ -192,3 +192,64 @@ def test_pix2pix_dropout_forward_and_backward_f32():
         # missing 1/keep would be O(1) in l2
         tol2 = max(1e-2, 5.0 * l2err(ref32[k].double().numpy(), v.numpy()))
         assert l2err(got[k], v.numpy()) < tol2, (k, tol2, l2err(got[k], v.numpy()))
+
+
+@pytest.mark.parametrize('which', [['input'], ['latent', 'end'], ['input', 'latent', 'end']])
+def test_pix2pix_noise_injection_f32(which):
+    """`--noise input|latent|end` (hem/models/pix2pix.py:183-186,204-206,223-225; examples/pix2pix/noise*.config): a
+    U(-1,1) tensor concatenated to the generator input (4 -> 64), to the 1x1 bottleneck (1024 -> 512) and to the last
+    decoder layer's input (129 -> 1).  With the uniform draws injected on both sides: G(x), and the U-Net's parameter
+    gradients from an injected dL/dG(x), against the float64 oracle -- including the filter slices that see only noise."""
+    p2p, rt, K = pkg('models.pix2pix'), pkg('runtime'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    B = 2
+    args = SimpleNamespace(model='pix2pix', batch_size=B, n_gpus=1, optimizer='rmsprop', lr=1e-4, decay=0.9, momentum=0.01,
+                           centered=False, beta1=0.5, beta2=0.999, n_disc_train=1, add_l1=False, batch_norm_gen=False,
+                           batch_norm_disc=False, dropout=0, noise=list(which))
+    P0 = PR.init_params(args, 0, np.float32)
+    shapes = {'input': (B, 256, 256, 1), 'latent': (B, 1, 1, 512), 'end': (B, 128, 128, 1)}
+    for k, want in (('generator/enocder/vars/1/weights', (4, 4, 4 if 'input' in which else 3, 64)),
+                    ('generator/decoder/vars/1/weights', (4, 4, 512, 1024 if 'latent' in which else 512)),
+                    ('generator/decoder/vars/8/weights', (4, 4, 1, 129 if 'end' in which else 128))):
+        assert P0[k].shape == want
+    rng = np.random.default_rng(8)
+    x01 = rng.uniform(0, 1, (B, 256, 256, 3)).astype(np.float32)
+    y01 = rng.uniform(0.01, 0.99, (B, 256, 256, 1)).astype(np.float32)
+    u01 = {k: rng.uniform(0, 1, shapes[k]).astype(np.float32) for k in which}          # the draws in [0, 1) as the device sees them
+    seed = rng.standard_normal((B, 256, 256, 1)).astype(np.float32) * 1e-3
+    sess = rt.Session(device=dev, dtype=K.F32, seed=0, rank=0, world_size=1)
+    model = p2p.pix2pix(PairSource([(x01, y01)], dev), args, sess)
+    assert set(model.g_store.index) | set(model.d_store.index) == set(P0)
+    model.load_variables(P0)
+    P = TR.to_torch(P0, torch.float64)
+    x = torch.tensor(2 * x01.astype(np.float64) - 1)
+    noise = {k: torch.tensor(2.0 * (u.astype(np.float64) - 0.5)) for k, u in u01.items()}
+    g = PR.generator(P, x, args, noise=noise)
+    gkeys = [k for k in P if k.startswith('generator/')]
+    ref = dict(zip(gkeys, torch.autograd.grad(g, [P[k] for k in gkeys], grad_outputs=torch.tensor(seed, dtype=torch.float64))))
+    P32 = TR.to_torch(P0, torch.float32)
+    g32 = PR.generator(P32, x.float(), args, noise={k: v.float() for k, v in noise.items()})
+    ref32 = dict(zip(gkeys, torch.autograd.grad(g32, [P32[k] for k in gkeys], grad_outputs=torch.tensor(seed))))
+
+    model._load((torch.tensor(x01, device=dev), torch.tensor(y01, device=dev)))
+    sess.inject = {'noise_' + k: [u] for k, u in u01.items()}
+    model.U.forward()
+    assert not any(sess.inject.values())                       # every requested draw consumed
+    slot1 = model.D.x.view(B, B).buf[:B * 256 * 256 * 8].view(B, 256, 256, 8)
+    assert np.abs(slot1[..., 3].cpu().numpy() - g.detach().numpy()[..., 0]).max() < 5e-4
+    dx1 = model.D.dx.view(B, B).buf[:B * 256 * 256 * 8].view(B, 256, 256, 8)
+    dx1.zero_()
+    dx1[..., 3] = torch.tensor(seed[..., 0], device=dev)
+    model.U.backward()
+    got = model.gradients()
+    for k, v in ref.items():
+        if k.endswith('/bias') and 'decoder' in k:
+            continue                                            # biases feeding batch norm
+        tol2 = max(1e-2, 5.0 * l2err(ref32[k].double().numpy(), v.numpy()))
+        assert l2err(got[k], v.numpy()) < tol2, (k, tol2, l2err(got[k], v.numpy()))
+    # a free-running train() with device-drawn noise: finite losses, fresh noise per generator pass (3 passes x |which| draws)
+    sess.inject = {}
+    d0 = sess.rng_state()
+    out = model.train(sess, args, None)
+    assert all(np.isfinite(v) for v in out.values())
+    assert sess.rng_state() - d0 == 3 * len(which)
