@@ -75,6 +75,7 @@ SIGNATURES = {
     'tdg_sumsq': (_i, [_i, _vp, _sz, _vp, _f, _vp, _sz, _vp]),
     'tdg_reduce_workspace_bytes': (_sz, [_sz]),
     'tdg_mean_f32': (_i, [_vp, _i, _vp, _vp]),
+    'tdg_mean_segments_f32': (_i, [_vp, _i, _i, _vp, _vp]),
     'tdg_gan_logloss': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'tdg_p2p_xent': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'tdg_p2p_l1': (_i, [_i, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),

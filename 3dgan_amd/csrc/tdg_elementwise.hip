@@ -107,6 +107,53 @@ __device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
   return r;
 }
 
+// ---- last-block tickets ------------------------------------------------------------------------------------------
+// One launch instead of two for "every block contributes, one block finishes": each block takes a ticket from a
+// device-global counter when it is done; the block that draws the last ticket does the finishing work and resets the
+// counter (self-cleaning, so hipGraph replays need no memset).  Kernels of one stream never overlap, and every kernel
+// family has its own slot.  `last_block_ticket`: no data is handed over (the finisher only needs to know that every
+// block has READ something: the Adam step count, the Philox draw counter).  `last_block_arrives`: the other blocks'
+// global stores are handed over -- producer: drain, barrier, agent-scope release, ticket; finisher: agent-scope acquire,
+// drain, barrier, then plain loads (MI355X_MICROARCH.md, inter-workgroup visibility).
+#define TICKET_SUMSQ 1024
+#define TICKET_ADAM 1025
+#define TICKET_RNG 1026
+#define TICKET_L1 1027
+__device__ unsigned g_ticket[1088];
+
+__device__ __forceinline__ bool last_block_ticket(unsigned slot, unsigned nblocks) {
+  __shared__ int s_last_t;
+  __syncthreads();                                   // every thread of the block is done with what the finisher will change
+  if (threadIdx.x == 0) {
+    const unsigned t = __hip_atomic_fetch_add(&g_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nblocks - 1;
+    if (last) __hip_atomic_store(&g_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last_t = last;
+  }
+  __syncthreads();
+  return s_last_t != 0;
+}
+
+__device__ __forceinline__ bool last_block_arrives(unsigned slot, unsigned nblocks) {
+  __shared__ int s_last_a;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&g_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = t == nblocks - 1;
+    if (last) {
+      __hip_atomic_store(&g_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    s_last_a = last;
+  }
+  __syncthreads();
+  return s_last_a != 0;
+}
+
 // ============================================================================ column reductions
 // partial[blk][v][c] = sum over the block's rows of f_v(row, c), v < 2.  2-D grid: blockIdx.x walks
 // row blocks, blockIdx.y walks column chunks of CL*VW channels; each lane owns VW consecutive
@@ -648,8 +695,10 @@ extern "C" int tdg_gp_interp(int dtype, const void* x, const void* g, const floa
 #define RED_BLOCKS 256
 extern "C" size_t tdg_reduce_workspace_bytes(size_t) { return RED_BLOCKS * sizeof(float); }
 
+// acc = beta * acc + sum x^2: per-block partials, summed by the block that arrives last in a fixed order (deterministic)
 template <typename T>
-__global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict__ x, size_t n, float* __restrict__ partial) {
+__global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict__ x, size_t n, float* __restrict__ partial,
+                                                           float* __restrict__ acc, float beta) {
   __shared__ float sh[4];
   float s = 0.f;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -658,14 +707,21 @@ __global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict_
   }
   s = block_sum256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
+  if (!last_block_arrives(TICKET_SUMSQ, gridDim.x)) return;
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += partial[i];
+  t = block_sum256(t, sh);
+  if (threadIdx.x == 0) acc[0] = (beta != 0.f ? beta * acc[0] : 0.f) + t;
 }
+// out[seg] = beta * out[seg] + scale * sum(x[seg * seglen ...]) : one block per segment
 __global__ void __launch_bounds__(256) reduce_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ acc,
                                                           float beta, float scale) {
   __shared__ float sh[4];
+  const float* p = partial + (size_t)blockIdx.x * np;
   float s = 0.f;
-  for (int i = threadIdx.x; i < np; i += 256) s += partial[i];
+  for (int i = threadIdx.x; i < np; i += 256) s += p[i];
   s = block_sum256(s, sh);
-  if (threadIdx.x == 0) acc[0] = (beta != 0.f ? beta * acc[0] : 0.f) + scale * s;
+  if (threadIdx.x == 0) acc[blockIdx.x] = (beta != 0.f ? beta * acc[blockIdx.x] : 0.f) + scale * s;
 }
 extern "C" int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* workspace,
                          size_t workspace_bytes, void* stream) {
@@ -673,11 +729,15 @@ extern "C" int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float b
   if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_sumsq: workspace too small"); return TDG_EWORKSPACE; }
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(x),
-                       n, static_cast<float*>(workspace));
+                       n, static_cast<float*>(workspace), acc, beta);
   })
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, static_cast<const float*>(workspace),
-                     RED_BLOCKS, acc, beta, 1.f);
   TDG_HIP_LAUNCH_CHECK("sumsq");
+  return TDG_OK;
+}
+extern "C" int tdg_mean_segments_f32(const float* x, int nseg, int seglen, float* out, void* stream) {
+  TDG_CHECK_ARG(x && out && nseg > 0 && nseg <= 65535 && seglen > 0, "tdg_mean_segments_f32: bad argument");
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, x, seglen, out, 0.f, 1.f / (float)seglen);
+  TDG_HIP_LAUNCH_CHECK("mean_segments_f32");
   return TDG_OK;
 }
 extern "C" int tdg_mean_f32(const float* x, int n, float* out, void* stream) {
@@ -1004,7 +1064,7 @@ extern "C" int tdg_adam_step(float* p, const float* g, float* m, float* v, size_
 
 __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, size_t n4, float lr, float b1, float b2, float eps,
-                                                      float gs, const int* __restrict__ t_dev) {
+                                                      float gs, int* __restrict__ t_dev) {
   const float t = (float)(t_dev[0] + 1);
   const float lr_t = lr * sqrtf(1.f - powf(b2, t)) / (1.f - powf(b1, t));
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -1018,9 +1078,11 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, co
     reinterpret_cast<f32x4*>(v)[i] = vv;
     reinterpret_cast<f32x4*>(p)[i] = pv;
   }
+  // every block has read the step count by the time it takes its ticket: the last one counts the step
+  if (last_block_ticket(TICKET_ADAM, gridDim.x) && threadIdx.x == 0) t_dev[0] += 1;
 }
 extern "C" int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                                 float eps, float grad_scale, const int32_t* t_dev, void* stream) {
+                                 float eps, float grad_scale, int32_t* t_dev, void* stream) {
   TDG_CHECK_ARG(p && g && m && v && t_dev && n > 0 && (n & 3) == 0, "tdg_adam_step_dev: bad argument (n must be a multiple of 4)");
   hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
                      beta1, beta2, eps, grad_scale, t_dev);
@@ -1233,7 +1295,7 @@ struct Philox {
 __device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }   // [0,1)
 
 template <typename T>
-__global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint64_t sid, uint64_t offset, const int* __restrict__ draw_dev,
+__global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint64_t sid, uint64_t offset, int* __restrict__ draw_dev,
                                                            size_t n, T* __restrict__ out) {
   if (draw_dev) offset = ((uint64_t)(unsigned)(draw_dev[0] + 1)) << 24;
   const size_t n4 = (n + 3) >> 2;
@@ -1253,18 +1315,20 @@ __global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint6
     for (int e = 0; e < 4; ++e)
       if (4 * i + e < n) out[4 * i + e] = from_f32<T>(z[e]);
   }
+  // device-counter form: the draw is counted by the block that finishes last (every block read the counter at its start)
+  if (draw_dev && last_block_ticket(TICKET_RNG, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
 }
 extern "C" int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, void* out,
                                  void* stream) {
   TDG_CHECK_ARG(out && n > 0, "tdg_random_normal: bad argument");
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(random_normal_kernel<T>, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                       stream_id, offset, (const int*)nullptr, n, static_cast<T*>(out));
+                       stream_id, offset, (int*)nullptr, n, static_cast<T*>(out));
   })
   TDG_HIP_LAUNCH_CHECK("random_normal");
   return TDG_OK;
 }
-extern "C" int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, void* out,
+extern "C" int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, void* out,
                                      void* stream) {
   TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_normal_dev: bad argument");
   DISPATCH_T(dtype, {
@@ -1276,7 +1340,7 @@ extern "C" int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_i
 }
 
 __global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint64_t sid, uint64_t offset,
-                                                            const int* __restrict__ draw_dev, size_t n, float* __restrict__ out) {
+                                                            int* __restrict__ draw_dev, size_t n, float* __restrict__ out) {
   if (draw_dev) offset = ((uint64_t)(unsigned)(draw_dev[0] + 1)) << 24;
   const size_t n4 = (n + 3) >> 2;
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
@@ -1286,15 +1350,16 @@ __global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint
     for (int e = 0; e < 4; ++e)
       if (4 * i + e < n) out[4 * i + e] = u01(ph.c[e]);
   }
+  if (draw_dev && last_block_ticket(TICKET_RNG, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
 }
 extern "C" int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out, void* stream) {
   TDG_CHECK_ARG(out && n > 0, "tdg_random_uniform_f32: bad argument");
   hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
-                     stream_id, offset, (const int*)nullptr, n, out);
+                     stream_id, offset, (int*)nullptr, n, out);
   TDG_HIP_LAUNCH_CHECK("random_uniform");
   return TDG_OK;
 }
-extern "C" int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, float* out,
+extern "C" int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, float* out,
                                           void* stream) {
   TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_uniform_f32_dev: bad argument");
   hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,

@@ -148,8 +148,7 @@ class Adam(Optimizer):
         """lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is derived in-kernel from the device-resident step count."""
         s = self.store
         _lib.call('tdg_adam_step_dev', K.ptr(s.params), K.ptr(s.grads), K.ptr(self.m), K.ptr(self.v), s.size,
-                  self.lr, self.b1, self.b2, self.eps, grad_scale, K.ptr(self.t_dev), K.stream())
-        _lib.call('tdg_add_i32', K.ptr(self.t_dev), 1, K.stream())
+                  self.lr, self.b1, self.b2, self.eps, grad_scale, K.ptr(self.t_dev), K.stream())     # counts the step itself
 
     def set_step_count(self, t):
         self.t_dev.fill_(int(t))

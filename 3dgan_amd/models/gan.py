@@ -200,8 +200,8 @@ class GanReplica(engine.GraphRunner):
 
     def _means(self, scores):
         R = self.B * self.rows_per_image
-        _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
-        _lib.call('tdg_mean_f32', K.ptr(scores, 4 * R), R, K.ptr(self.scal, 4 * self.S_DFAKE), K.stream())
+        # scores = [D(x) | D(g) | ...] and the slots S_DREAL, S_DFAKE are adjacent: both means in one launch
+        _lib.call('tdg_mean_segments_f32', K.ptr(scores, 0), 2, R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
 
     def _seeds(self, *values):
         """Constant dL/d(score) seeds of slots 0..len-1 (None: a slot this pass does not read).  Every distinct

@@ -43,9 +43,9 @@ class Session:
 
     # ---- RNG (tf.random_normal / tf.random_uniform, models/gan.py:246,224) ---------
     def _bump_draws(self):
-        """The draw counter lives in device memory so that a captured hipGraph replays fresh streams."""
+        """The draw counter lives in device memory so that a captured hipGraph replays fresh streams; the RNG kernels
+        count their own draw (tdg_random_*_dev), this is only the host's mirror of eagerly issued draws."""
         self._draws += 1
-        _lib.call('tdg_add_i32', K.ptr(self._draws_dev), 1, K.stream())
 
     def _injected(self, key):
         q = self.inject.get(key)

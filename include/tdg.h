@@ -188,6 +188,8 @@ int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* 
 size_t tdg_reduce_workspace_bytes(size_t n);
 /* out[0] = mean(x[0:n]) f32 input (tf.reduce_mean of D outputs, models/gan.py:196-204) */
 int tdg_mean_f32(const float* x, int n, float* out, void* stream);
+/* out[s] = mean(x[s*seglen : (s+1)*seglen]) for s < nseg, one launch (the means of D(x) and D(g), :196-197) */
+int tdg_mean_segments_f32(const float* x, int nseg, int seglen, float* out, void* stream);
 /* Vanilla-GAN losses on post-sigmoid scores (models/gan.py:193-194) and their gradients w.r.t. the LOGITS:
  *   scal[0] = d_loss = mean(-log(dr+1e-8) - log(1-df+1e-8)),  scal[1] = g_loss = mean(-log(df+1e-8))
  *   seed_real = d d_loss/d logit_real, seed_fake_d = d d_loss/d logit_fake, seed_fake_g = d g_loss/d logit_fake */
@@ -244,10 +246,10 @@ int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs, float* db,
 int tdg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float beta1,
                   float beta2, float eps, float grad_scale, void* stream);
 /* Same update with the step count t kept in device memory (t_dev[0] = number of steps already applied):
- * lr_t is derived in-kernel, so a captured hipGraph can be replayed without re-baking arguments.
- * Follow with tdg_add_i32(t_dev, 1). */
+ * lr_t is derived in-kernel, so a captured hipGraph can be replayed without re-baking arguments, and the kernel itself
+ * counts the step (t_dev[0] += 1, by its last block). */
 int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
-                      float beta2, float eps, float grad_scale, const int32_t* t_dev, void* stream);
+                      float beta2, float eps, float grad_scale, int32_t* t_dev, void* stream);
 int tdg_add_i32(int32_t* x, int32_t inc, void* stream);
 /* RMSProp (rms slot initialised to 1 by the caller), optional momentum, not centered */
 int tdg_rmsprop_step(float* p, const float* g, float* rms, float* mom, size_t n, float lr,
@@ -279,11 +281,11 @@ int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t off
                       void* out, void* stream);
 int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out,
                            void* stream);
-/* Graph-replayable forms: the counter offset is (draw_dev[0] << 24), read from device memory;
- * follow each draw with tdg_add_i32(draw_dev, 1). */
-int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n,
+/* Graph-replayable forms: the counter offset is ((draw_dev[0] + 1) << 24), read from device memory, and the kernel
+ * itself counts the draw (draw_dev[0] += 1, by its last block), so a replay of the same launch is a fresh draw. */
+int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n,
                           void* out, void* stream);
-int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, const int32_t* draw_dev, size_t n, float* out,
+int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, float* out,
                                void* stream);
 
 /* ---- input pipeline, host side (no GPU work): PNG scanline reconstruction (filter types 0-4 of the PNG
