@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('TDG_LIB_PATH') or os.path.join(_HERE, 'lib3dgan_hip.s
 F32, BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4
 MASK_NONE, MASK_LRELU, MASK_RELU = 0, 1, 2
+COL_NONE, COL_SUM, COL_BN = 0, 1, 2
 
 
 class ConvDesc(C.Structure):
@@ -25,7 +26,9 @@ class ConvDesc(C.Structure):
 class Epilogue(C.Structure):
     """TdgEpilogue (include/tdg.h)."""
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('leak', C.c_float),
-                ('mask_mode', C.c_int32), ('mask_src', C.c_void_p), ('accumulate', C.c_int32)]
+                ('mask_mode', C.c_int32), ('mask_src', C.c_void_p), ('accumulate', C.c_int32),
+                ('col_partial', C.c_void_p), ('col_partial_bytes', C.c_size_t), ('col_mode', C.c_int32),
+                ('col_images', C.c_int32), ('col_nblk_out', C.POINTER(C.c_int32))]
 
 
 class PackJob(C.Structure):
@@ -60,6 +63,8 @@ SIGNATURES = {
     'tdg_conv2d_bwd_filter2': (_i, [_PD, _i, _vp, _i, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_rowdot': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'tdg_rowouter': (_i, [_i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
+    'tdg_col_finalize_sum': (_i, [_vp, _i, _i, _vp, _f, _vp]),
+    'tdg_bn_fwd_from_partials': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     'tdg_colsum_weighted': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_colsum_workspace_bytes': (_sz, [_i, _i]),
     'tdg_bn_workspace_bytes': (_sz, [_i, _i]),

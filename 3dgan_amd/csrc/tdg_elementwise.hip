@@ -287,6 +287,7 @@ enum { FIN_BN_STATS = 0, FIN_BN_BWD = 1, FIN_ACC = 2 };
 struct FinArgs {
   const float* partial; int nblk, C, rows;
   const void* x0;       // first row of the tensor (pivot) for BN stats
+  const float* pivot_f; // ... or an f32 pivot row (the producing conv's bias) when the partials came from its epilogue; both null: 0
   float eps;
   float* out0;          // stats (mean | rstd)   / dbeta / dw
   float* out1;          // bwd: mean sums [2][C] for the apply pass
@@ -323,7 +324,7 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   for (int k = 0; k < 32; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
   const float inv = 1.f / (float)a.rows;
   if (MODE == FIN_BN_STATS) {
-    const float pivot = to_f32<T>(static_cast<const T*>(a.x0)[c]);
+    const float pivot = a.pivot_f ? a.pivot_f[c] : (a.x0 ? to_f32<T>(static_cast<const T*>(a.x0)[c]) : 0.f);
     const float md = s0 * inv;
     const float var = fmaxf(s1 * inv - md * md, 0.f);
     a.out0[c] = pivot + md;
@@ -445,6 +446,38 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
                          leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
   })
   TDG_HIP_LAUNCH_CHECK("bn_fwd");
+  return TDG_OK;
+}
+
+extern "C" int tdg_col_finalize_sum(const float* partial, int nblk, int c, float* out, float beta, void* stream) {
+  TDG_CHECK_ARG(partial && out && nblk > 0 && c > 0, "tdg_col_finalize_sum: bad argument");
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = partial; f.nblk = nblk; f.C = c; f.rows = 1; f.out0 = out; f.beta_acc = beta;
+  hipLaunchKernelGGL((col_finalize_kernel<float, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, f);
+  TDG_HIP_LAUNCH_CHECK("col_finalize_sum");
+  return TDG_OK;
+}
+
+extern "C" int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
+                                        float leak, void* pre, void* h, int h_cs, float* stats, const float* partial, int nblk,
+                                        const float* pivot_bias, void* stream) {
+  TDG_CHECK_ARG(u && beta && pre && h && stats && partial && nblk > 0, "tdg_bn_fwd_from_partials: null pointer");
+  TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c && h_cs >= c, "tdg_bn_fwd_from_partials: bad shape rows=%d c=%d cs=%d h_cs=%d", rows, c, cs, h_cs);
+  hipStream_t s = (hipStream_t)stream;
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = partial; f.nblk = nblk; f.C = c; f.rows = rows; f.x0 = nullptr; f.pivot_f = pivot_bias; f.eps = eps; f.out0 = stats;
+  const ColGeom ga = col_geom(rows, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), tdg_dtype_size(dtype), h_cs % 4 == 0);
+  const dim3 agrid(apply_row_blocks(ga), ga.ncol);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    if (ga.vw == 4)
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
+    else
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
+  })
+  TDG_HIP_LAUNCH_CHECK("bn_fwd_from_partials");
   return TDG_OK;
 }
 

@@ -39,6 +39,9 @@ struct IgArgs {
   float leak;
   int ntiles_n, ntiles_m_max, nclasses;
   int n_begin;           // first output column of this launch (a problem's columns may be split over launches)
+  float* col_partial;    // per row tile [2][N] column sums of the stored tile (TdgEpilogue.col_partial), or null
+  int col_mode;          // TDG_COL_*
+  int col_images;        // rows of images >= col_images do not count (0: all)
   unsigned long long* stamps;  // diagnostic build (-DTDG_STAMPS) only: per-wave cycle sums; null otherwise
   int debug;             // TDG_DEBUG_ABLATE (diagnostics only): 1 no global loads in loop, 2 + no LDS stores, 3 no MFMA
   IgClass cls[IG_MAX_CLASSES];

@@ -526,7 +526,14 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
   const int tile_m = bid / args.ntiles_n;
   const int tile_n = bid - tile_m * args.ntiles_n;
   const int M = cl.M;
-  if (tile_m * BM >= M) return;
+  if (tile_m * BM >= M) {                              // a class with fewer rows than the largest: its partial rows are zeros
+    if (args.col_partial && tid < BN) {
+      const int n = args.n_begin + tile_n * BN + tid;
+      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * args.N;
+      if (n < args.N) { pr[n] = 0.f; pr[args.N + n] = 0.f; }
+    }
+    return;
+  }
   const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -819,11 +826,44 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
         if (mmode != TDG_MASK_NONE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[it][e] > 0.f ? 1.f : mlow));
+          if (args.col_partial) *reinterpret_cast<bf16x8*>(sE + row * PE + cc * 16) = v;     // the sums are of what is stored
         }
         if (n + 8 <= N) {
           *reinterpret_cast<bf16x8*>(out + p + n) = v;
         } else {
           *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
+        }
+      }
+      if (args.col_partial) {
+        // Column partials of the stored tile (TdgEpilogue.col_partial): NTHR / BN thread groups walk interleaved rows of
+        // one column each, the groups are summed in a fixed order (deterministic).  TDG_COL_BN: deviations from the bias.
+        constexpr int G = NTHR / BN > 0 ? NTHR / BN : 1;
+        float* sRed = reinterpret_cast<float*>(smem + BM * PE + BM * 8);
+        static_assert(BM * PE + BM * 8 + 2 * G * BN * 4 <= NS * STAGE, "column partials must fit the ring");
+        __syncthreads();
+        const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW) : M;
+        const int rows_valid = max(0, min(BM, mlim - m0));
+        const int col = tid % BN, grp = tid / BN;
+        const bool bnm = args.col_mode == TDG_COL_BN;
+        if (grp < G) {
+          const float piv = bnm ? sBias[col] : 0.f;
+          float s0 = 0.f, s1 = 0.f;
+          for (int r = grp; r < rows_valid; r += G) {
+            const float v = (float)*reinterpret_cast<const bf16_t*>(sE + r * PE + col * 2) - piv;
+            s0 += v;
+            s1 += v * v;
+          }
+          sRed[(grp * 2 + 0) * BN + col] = s0;
+          sRed[(grp * 2 + 1) * BN + col] = s1;
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < N) {
+          float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+          for (int g = 0; g < G; ++g) { t0 += sRed[(g * 2 + 0) * BN + tid]; t1 += sRed[(g * 2 + 1) * BN + tid]; }
+          float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * N;
+          pr[n0 + tid] = t0;
+          pr[N + n0 + tid] = t1;
         }
       }
 #ifdef TDG_STAMPS
@@ -2057,6 +2097,7 @@ __global__ void __launch_bounds__(256) pack_thin_kernel(const ThinPackArgs a) {
 namespace {
 
 thread_local double t_flops = 0.0;   // algorithmic FLOPs of the entry-point call being dispatched (for tdg_timing_*)
+thread_local const TdgEpilogue* t_col = nullptr;   // column-partial request of the call being dispatched (fill_epilogue)
 
 struct TileCfg { int bm, bn; };
 
@@ -2090,6 +2131,15 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   a.n_begin = n_begin;
   a.ntiles_n = ntiles_n < 0 ? tdg_ceil_div(a.N, BN) : ntiles_n;
   a.ntiles_m_max = tdg_ceil_div(mmax, BM);
+  if (t_col && sizeof(T) == 2 && !a.accumulate && (a.N & 3) == 0 && n_begin == 0 && a.ntiles_n * BN >= a.N) {
+    const int nblk = a.nclasses * a.ntiles_m_max;
+    if ((size_t)nblk * 2 * a.N * sizeof(float) <= t_col->col_partial_bytes) {
+      a.col_partial = t_col->col_partial;
+      a.col_mode = t_col->col_mode;
+      a.col_images = t_col->col_images;
+      *t_col->col_nblk_out = nblk;
+    }
+  }
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
   const size_t lds = NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int) + BNL * sizeof(float);   // ring, taps, bias row
   static_assert(NS * (size_t)(BM + BNL) * IG_BKB + IG_MAX_TAPS * sizeof(int) + BNL * sizeof(float) <= 160 * 1024, "LDS budget");
@@ -2630,6 +2680,15 @@ static void fill_epilogue(IgArgs& a, const TdgEpilogue* epi) {
   a.mask_src = epi ? epi->mask_src : nullptr;
   a.accumulate = epi ? epi->accumulate : 0;
   if (a.mask_mode == TDG_MASK_NONE) a.mask_src = nullptr;
+  // column partials: granted by launch_fwd_dma when the chosen kernel has the staged bf16 epilogue, else reported as 0 tiles
+  a.col_partial = nullptr;
+  a.col_mode = TDG_COL_NONE;
+  a.col_images = 0;
+  t_col = nullptr;
+  if (epi && epi->col_partial && epi->col_mode != TDG_COL_NONE && epi->col_nblk_out) {
+    *epi->col_nblk_out = 0;
+    t_col = epi;
+  }
 }
 
 int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void* wp, void* y,

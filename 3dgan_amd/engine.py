@@ -388,7 +388,8 @@ class SeqNet:
                 continue
             bias = self.store[L.bname]
             if L.spec.use_bn:
-                epi = K.epilogue(bias=bias)
+                # the GEMM's epilogue also emits the batch statistics' column partials of the tile it stores
+                epi = K.colsum_epilogue(self.ws, rn * L.h.h * L.h.w, L.spec.out_size, K.COL_BN, bias=bias)
                 target = L.pre
             else:
                 epi = K.epilogue(bias=bias, act=L.act.code, leak=L.act.leak)
@@ -399,9 +400,14 @@ class SeqNet:
                 L.conv.fwd(L.inp.ptr(r0), target.ptr(r0), rn, epi)
             if L.spec.use_bn:
                 rows = rn * L.h.h * L.h.w
-                K.bn_fwd(self.ws, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
-                         L.bn_stats[bn_pass], rows=rows, leak=L.act.leak,
-                         u_ptr=L.pre.ptr(r0), pre_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
+                if K.nblk(epi):
+                    K.bn_fwd_from_partials(epi, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
+                                           L.bn_stats[bn_pass], bias, rows=rows, leak=L.act.leak,
+                                           u_ptr=L.pre.ptr(r0), pre_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
+                else:                                  # (f32 tiles, thin layers: the separate statistics pass)
+                    K.bn_fwd(self.ws, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
+                             L.bn_stats[bn_pass], rows=rows, leak=L.act.leak,
+                             u_ptr=L.pre.ptr(r0), pre_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
         last = self.layers[-1]
         return last.out if last.rowdot else last.h
 
@@ -415,6 +421,7 @@ class SeqNet:
         beta = 1.0 if acc else 0.0
         p0, pn = (img0, n) if param_images is None else param_images
         g = self.store.grad
+        have_db = None          # (layer, epilogue) whose backward-data GEMM has just emitted that layer's bias-gradient partials
         for L in reversed(self.layers):
             r0, rn = img0 * L.rpi, n * L.rpi
             q0, qn = p0 * L.rpi, pn * L.rpi
@@ -457,7 +464,10 @@ class SeqNet:
                 _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,
                           L.act.leak, L.delta.ptr(r0), K.stream())
             if want_params and qn > 0:
-                K.bias_grad(self.ws, L.delta, L.spec.out_size, g(L.bname), rows=qn * hw, beta=beta, dy_ptr=L.delta.ptr(q0))
+                if have_db is not None and have_db[0] is L and K.nblk(have_db[1]):
+                    K.bias_grad_from_partials(have_db[1], L.spec.out_size, g(L.bname), beta)
+                else:
+                    K.bias_grad(self.ws, L.delta, L.spec.out_size, g(L.bname), rows=qn * hw, beta=beta, dy_ptr=L.delta.ptr(q0))
                 if defer_wgrad:
                     pass
                 elif L.spec.kind == 'deconv2d':
@@ -465,7 +475,19 @@ class SeqNet:
                 else:
                     L.conv.bwd_filter(L.inp.ptr(q0), L.delta.ptr(q0), g(L.wname), qn, beta)
             if need_in:
-                epi = K.epilogue(mask_mode=mmode, leak=mleak, mask_src=msrc.ptr(dimg * below.rpi) if msrc is not None else None)
+                mptr = msrc.ptr(dimg * below.rpi) if msrc is not None else None
+                # what this GEMM stores IS delta of the layer below when that layer has no batch norm and a (l)relu / identity
+                # activation: its bias gradient = the column sums of the stored tiles, restricted to the parameter images
+                fuse = (want_params and below is not None and not below.rowdot and not below.spec.use_bn and
+                        below.act.code in (K.ACT_LRELU, K.ACT_RELU, K.ACT_NONE) and below.gout is below.delta and
+                        L.rpi == 1 and below.rpi == 1 and p0 == img0 and 0 < pn <= n and (d0, dn) == (r0, rn))
+                if fuse:
+                    epi = K.colsum_epilogue(self.ws, dn * below.h.h * below.h.w, below.spec.out_size, K.COL_SUM,
+                                            images=(pn if pn < n else 0), mask_mode=mmode, leak=mleak, mask_src=mptr)
+                    have_db = (below, epi)
+                else:
+                    epi = K.epilogue(mask_mode=mmode, leak=mleak, mask_src=mptr)
+                    have_db = None
                 if L.spec.kind == 'deconv2d':
                     L.conv.fwd(L.delta.ptr(d0), L.gin.ptr(d0), dn, epi)
                 else:

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (F32, BF16, ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH, ACT_SIGMOID,  # noqa: F401
-                   MASK_NONE, MASK_LRELU, MASK_RELU, ConvDesc, Epilogue)
+                   MASK_NONE, MASK_LRELU, MASK_RELU, COL_NONE, COL_SUM, COL_BN, ConvDesc, Epilogue)
 
 TORCH_DTYPE = {F32: torch.float32, BF16: torch.bfloat16}
 ELEM_SIZE = {F32: 4, BF16: 2}
@@ -94,6 +94,34 @@ def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=No
     e.act, e.leak, e.mask_mode = act, leak, mask_mode
     e.mask_src = mask_src if isinstance(mask_src, int) or mask_src is None else mask_src.value
     return e
+
+
+def colsum_epilogue(ws, rows, c, mode, images=0, **kw):
+    """An epilogue that also asks the GEMM for per-row-tile column partials of the tile it stores (TdgEpilogue.col_partial):
+    COL_SUM = the bias gradient of the tensor's layer, COL_BN = its batch statistics.  After the launch `nblk(e)` tells how
+    many row tiles were written (0: the kernel variant chosen for this launch cannot -- run the separate reduction pass)."""
+    e = epilogue(**kw)
+    nblk_max = rows // 64 + 8                       # row tiles are >= 64 rows; <= 4 parity classes round up separately
+    nbytes = nblk_max * 2 * c * 4
+    buf = ws.ensure(nbytes)
+    e.col_partial, e.col_partial_bytes, e.col_mode, e.col_images = buf.data_ptr(), nbytes, mode, images
+    e._nblk = C.c_int32(0)
+    e.col_nblk_out = C.pointer(e._nblk)
+    return e
+
+
+def nblk(e):
+    return int(e._nblk.value) if hasattr(e, '_nblk') else 0
+
+
+def bias_grad_from_partials(e, c, db, beta=0.0):
+    _lib.call('tdg_col_finalize_sum', C.c_void_p(e.col_partial), nblk(e), c, ptr(db), beta, stream())
+
+
+def bn_fwd_from_partials(e, u, c, beta, act, pre, h, stats, bias, rows=None, leak=0.2, eps=1e-3, u_ptr=None, pre_ptr=None, h_ptr=None):
+    rows = u.rows if rows is None else rows
+    _lib.call('tdg_bn_fwd_from_partials', u.dtype, u_ptr or u.ptr(), rows, c, u.cs, ptr(beta), eps, act, leak,
+              pre_ptr or pre.ptr(), h_ptr or h.ptr(), h.cs, ptr(stats), C.c_void_p(e.col_partial), nblk(e), ptr(bias), stream())
 
 
 class GemmTimer:

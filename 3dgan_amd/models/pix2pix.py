@@ -458,20 +458,29 @@ class UNet:
             src = self.x_in if k == 1 else self.e_h[k - 1]
             bias = st[self.enet.var_name(spec, 'bias')]
             if self.enc_bn[k - 1]:
-                conv.fwd(src.ptr(), self.e_pre[k].ptr(), B, K.epilogue(bias=bias))
-                K.bn_fwd(self.ws, self.e_pre[k], spec.out_size, st[self.e_bn_name[k]], spec.act.code, self.e_pre[k], self.e_h[k],
-                         self.e_stats[k], leak=spec.act.leak)
+                epi = K.colsum_epilogue(self.ws, self.e_pre[k].rows, spec.out_size, K.COL_BN, bias=bias)
+                conv.fwd(src.ptr(), self.e_pre[k].ptr(), B, epi)
+                self._bn_fwd(epi, self.e_pre[k], spec, st[self.e_bn_name[k]], self.e_h[k], self.e_stats[k], bias)
             else:
                 conv.fwd(src.ptr(), self.e_h[k].ptr(), B, K.epilogue(bias=bias, act=spec.act.code, leak=spec.act.leak))
         for i in range(1, 9):
             spec, conv = Dc[i - 1], self.d_conv[i]
             src = self._d_in(i)
-            conv.bwd_data(src.ptr(), self.d_pre[i].ptr(), B, K.epilogue(bias=st[self.dnet.var_name(spec, 'bias')]))
-            K.bn_fwd(self.ws, self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], spec.act.code, self.d_pre[i], self.d_h[i],
-                     self.d_stats[i], leak=spec.act.leak)
+            bias = st[self.dnet.var_name(spec, 'bias')]
+            epi = K.colsum_epilogue(self.ws, self.d_pre[i].rows, spec.out_size, K.COL_BN, bias=bias)
+            conv.bwd_data(src.ptr(), self.d_pre[i].ptr(), B, epi)
+            self._bn_fwd(epi, self.d_pre[i], spec, st[self.d_bn_name[i]], self.d_h[i], self.d_stats[i], bias)
             if self.d_keep[i] > 0:
                 self.sess.random_uniform(self.d_u[i], self.d_u[i].numel(), 'dropout')
                 self._dropout(self.d_h[i], i)
+
+    def _bn_fwd(self, epi, pre, spec, beta, h, stats, bias):
+        """Batch norm + activation of a layer whose GEMM has just stored `pre`: statistics from the epilogue's column
+        partials when the launch provided them, else by the separate pass."""
+        if K.nblk(epi):
+            K.bn_fwd_from_partials(epi, pre, spec.out_size, beta, spec.act.code, pre, h, stats, bias, leak=spec.act.leak)
+        else:
+            K.bn_fwd(self.ws, pre, spec.out_size, beta, spec.act.code, pre, h, stats, leak=spec.act.leak)
 
     def _dropout(self, act, i):
         rows = self.B * act.h * act.w

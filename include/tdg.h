@@ -71,7 +71,22 @@ typedef struct TdgEpilogue {
   int32_t mask_mode;        /* TDG_MASK_*                                    */
   const void* mask_src;     /* tensor with the geometry of the output, dtype = desc.dtype */
   int32_t accumulate;       /* 1: out = (act(acc + bias) + out) * mask  -- sums a second gradient path (U-Net skips) */
+  /* Column partials of the STORED tile, emitted by the epilogue that holds it anyway (instead of a separate pass over
+   * the tensor): per workgroup row tile b,  col_partial[(b*2 + 0)*N + n] = sum over its rows,  [(b*2 + 1)*N + n] = the
+   * second moment (TDG_COL_BN).  TDG_COL_SUM: sum of the stored values (after activation and mask) = the bias gradient
+   * of the layer that owns the tensor (autodiff of tf.nn.bias_add, ops/layers.py:102).  TDG_COL_BN: sum (v - bias[n]) and
+   * sum (v - bias[n])^2 of the stored pre-activation = the batch statistics of tf.contrib.layers.batch_norm
+   * (ops/layers.py:103,144).  Only rows of images < col_images count (0: all).  The launch reports how many row
+   * tiles it wrote in *col_nblk_out (host memory, written before the call returns); 0 = this launch's kernel
+   * variant does not provide partials (f32 tiles, accumulating epilogues, thin layers): run the separate pass.
+   * Finish with tdg_col_finalize_sum / tdg_bn_fwd_from_partials. */
+  float* col_partial;
+  size_t col_partial_bytes;
+  int32_t col_mode;         /* TDG_COL_*                                     */
+  int32_t col_images;
+  int32_t* col_nblk_out;
 } TdgEpilogue;
+enum { TDG_COL_NONE = 0, TDG_COL_SUM = 1, TDG_COL_BN = 2 };
 
 const char* tdg_last_error(void);
 int tdg_version(void);
@@ -145,6 +160,9 @@ int tdg_rowdot(int dtype, const void* x, int rows, int cols, const float* w, con
 /* dx[r, c] = (dout[r] * w[c]) * mask(mask_src[r, c]) */
 int tdg_rowouter(int dtype, const float* dout, const float* w, int rows, int cols, int mask_mode,
                  float leak, const void* mask_src, void* dx, void* stream);
+/* Finish column partials written by a conv epilogue (TdgEpilogue.col_partial, nblk row tiles, c columns):
+ * out[n] = beta*out[n] + sum_b partial[(b*2)*c + n], fixed summation order. */
+int tdg_col_finalize_sum(const float* partial, int nblk, int c, float* out, float beta, void* stream);
 /* dw[c] = beta*dw[c] + sum_r coef[r] * x[r, c]   (coef NULL -> 1); deterministic */
 int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols, int cs, const float* coef,
                         float* dw, float beta, void* workspace, size_t workspace_bytes, void* stream);
@@ -161,6 +179,11 @@ size_t tdg_bn_workspace_bytes(int rows, int c);
 int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps,
                int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
                size_t workspace_bytes, void* stream);
+/* tdg_bn_fwd with the batch statistics taken from TDG_COL_BN partials of the producing conv (pivot = that conv's
+ * bias, may be NULL) instead of a pass over u: stats, then pre = (u - mean) * rstd + beta and h = act(pre). */
+int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
+                             float leak, void* pre, void* h, int h_cs, float* stats, const float* partial, int nblk,
+                             const float* pivot_bias, void* stream);
 int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre, int rows, int c, int cs,
                const float* beta, const float* stats, int act, float leak, void* du, float* dbeta,
                float beta_acc, void* workspace, size_t workspace_bytes, void* stream);
