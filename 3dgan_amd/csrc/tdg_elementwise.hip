@@ -119,14 +119,30 @@ __device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
 #define TICKET_ADAM 1025
 #define TICKET_RNG 1026
 #define TICKET_L1 1027
-__device__ unsigned g_ticket[1088];
+#define TICKET_ADAM_SUB 1088
+#define TICKET_RNG_SUB 1152
+__device__ unsigned g_ticket[1216];
 
-__device__ __forceinline__ bool last_block_ticket(unsigned slot, unsigned nblocks) {
+// Two levels above 64 blocks: 4096 tickets on ONE word cost ~46 us (a word takes ~88 atomics per us); 64 sub-counters of
+// <= 64 tickets each plus 64 tickets on the top word cost ~1.5 us.
+__device__ __forceinline__ bool last_block_ticket(unsigned slot, unsigned sub_base, unsigned nblocks) {
   __shared__ int s_last_t;
   __syncthreads();                                   // every thread of the block is done with what the finisher will change
   if (threadIdx.x == 0) {
-    const unsigned t = __hip_atomic_fetch_add(&g_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = t == nblocks - 1;
+    int last = 0;
+    if (nblocks <= 64) {
+      const unsigned t = __hip_atomic_fetch_add(&g_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = t == nblocks - 1;
+    } else {
+      const unsigned sub = blockIdx.x & 63u;
+      const unsigned gsize = nblocks / 64u + (sub < (nblocks & 63u) ? 1u : 0u);
+      const unsigned t = __hip_atomic_fetch_add(&g_ticket[sub_base + sub], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == gsize - 1) {
+        __hip_atomic_store(&g_ticket[sub_base + sub], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t2 = __hip_atomic_fetch_add(&g_ticket[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t2 == 63u;
+      }
+    }
     if (last) __hip_atomic_store(&g_ticket[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last_t = last;
   }
@@ -552,14 +568,52 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
 }
 
 // ============================================================================ row ops (fc2)
-template <typename T>
+// VW elements (16 bytes) of a row per access: bf16 8, f32 4
+template <typename T> struct RowVec;
+template <> struct RowVec<bf16_t> {
+  static constexpr int VW = 8;
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+    *reinterpret_cast<bf16x8*>(p) = bf16x8{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3], (bf16_t)v[4], (bf16_t)v[5], (bf16_t)v[6], (bf16_t)v[7]};
+  }
+};
+template <> struct RowVec<float> {
+  static constexpr int VW = 4;
+  static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = t[e];
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&v)[4]) { *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; }
+};
+
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) rowdot_kernel(const T* __restrict__ x, int rows, int cols, const float* __restrict__ w,
                                                     const float* __restrict__ bias, int act, float* __restrict__ out) {
   __shared__ float sh[4];
+  constexpr int VW = RowVec<T>::VW;
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const T* xr = x + (size_t)r * cols;
     float s = 0.f;
-    for (int c = threadIdx.x; c < cols; c += 256) s += to_f32<T>(xr[c]) * w[c];
+    if constexpr (VEC) {
+      for (int c = threadIdx.x * VW; c < cols; c += 256 * VW) {
+        float v[VW], wv[VW];
+        RowVec<T>::load(xr + c, v);
+#pragma unroll
+        for (int e = 0; e < VW; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w + c + e);
+          wv[e] = t[0]; wv[e + 1] = t[1]; wv[e + 2] = t[2]; wv[e + 3] = t[3];
+        }
+#pragma unroll
+        for (int e = 0; e < VW; ++e) s += v[e] * wv[e];
+      }
+    } else {
+      for (int c = threadIdx.x; c < cols; c += 256) s += to_f32<T>(xr[c]) * w[c];
+    }
     s = block_sum256(s, sh);
     if (threadIdx.x == 0) out[r] = apply_act(s + (bias ? bias[0] : 0.f), act, 0.f);
   }
@@ -569,24 +623,49 @@ extern "C" int tdg_rowdot(int dtype, const void* x, int rows, int cols, const fl
                           float* out, void* stream) {
   TDG_CHECK_ARG(x && w && out && rows > 0 && cols > 0, "tdg_rowdot: bad argument");
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(rowdot_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const T*>(x), rows, cols, w, bias, act, out);
+    const bool vec = cols % RowVec<T>::VW == 0 && (((uintptr_t)x | (uintptr_t)w) & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL((rowdot_kernel<T, true>), dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                         static_cast<const T*>(x), rows, cols, w, bias, act, out);
+    else
+      hipLaunchKernelGGL((rowdot_kernel<T, false>), dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                         static_cast<const T*>(x), rows, cols, w, bias, act, out);
   })
   TDG_HIP_LAUNCH_CHECK("rowdot");
   return TDG_OK;
 }
 
-template <typename T>
+template <typename T, bool VEC>
 __global__ void __launch_bounds__(256) rowouter_kernel(const float* __restrict__ dout, const float* __restrict__ w, int rows,
                                                       int cols, int mask_mode, float leak, const T* __restrict__ msk,
                                                       T* __restrict__ dx) {
+  constexpr int VW = RowVec<T>::VW;
+  const float mlow = mask_low(mask_mode, leak);
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float d = dout[r];
-    for (int c = threadIdx.x; c < cols; c += 256) {
-      const size_t i = (size_t)r * cols + c;
-      float v = d * w[c];
-      if (mask_mode != TDG_MASK_NONE) v *= mask_factor(to_f32<T>(msk[i]), mask_mode, leak);
-      dx[i] = from_f32<T>(v);
+    if constexpr (VEC) {
+      for (int c = threadIdx.x * VW; c < cols; c += 256 * VW) {
+        const size_t i = (size_t)r * cols + c;
+        float v[VW], m[VW];
+#pragma unroll
+        for (int e = 0; e < VW; e += 4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(w + c + e);
+          v[e] = d * t[0]; v[e + 1] = d * t[1]; v[e + 2] = d * t[2]; v[e + 3] = d * t[3];
+        }
+        if (mask_mode != TDG_MASK_NONE) {
+          RowVec<T>::load(msk + i, m);
+#pragma unroll
+          for (int e = 0; e < VW; ++e) v[e] *= m[e] > 0.f ? 1.f : mlow;
+        }
+        RowVec<T>::store(dx + i, v);
+      }
+    } else {
+      for (int c = threadIdx.x; c < cols; c += 256) {
+        const size_t i = (size_t)r * cols + c;
+        float v = d * w[c];
+        if (mask_mode != TDG_MASK_NONE) v *= mask_factor(to_f32<T>(msk[i]), mask_mode, leak);
+        dx[i] = from_f32<T>(v);
+      }
     }
   }
 }
@@ -596,8 +675,13 @@ extern "C" int tdg_rowouter(int dtype, const float* dout, const float* w, int ro
   TDG_CHECK_ARG(dout && w && dx && rows > 0 && cols > 0, "tdg_rowouter: bad argument");
   TDG_CHECK_ARG(mask_mode == TDG_MASK_NONE || mask_src, "tdg_rowouter: mask without mask_src");
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(rowouter_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, dout, w, rows,
-                       cols, mask_mode, leak, static_cast<const T*>(mask_src), static_cast<T*>(dx));
+    const bool vec = cols % RowVec<T>::VW == 0 && (((uintptr_t)w | (uintptr_t)mask_src | (uintptr_t)dx) & 15) == 0;
+    if (vec)
+      hipLaunchKernelGGL((rowouter_kernel<T, true>), dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, dout, w,
+                         rows, cols, mask_mode, leak, static_cast<const T*>(mask_src), static_cast<T*>(dx));
+    else
+      hipLaunchKernelGGL((rowouter_kernel<T, false>), dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream, dout, w,
+                         rows, cols, mask_mode, leak, static_cast<const T*>(mask_src), static_cast<T*>(dx));
   })
   TDG_HIP_LAUNCH_CHECK("rowouter");
   return TDG_OK;
@@ -1112,7 +1196,7 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, co
     reinterpret_cast<f32x4*>(p)[i] = pv;
   }
   // every block has read the step count by the time it takes its ticket: the last one counts the step
-  if (last_block_ticket(TICKET_ADAM, gridDim.x) && threadIdx.x == 0) t_dev[0] += 1;
+  if (last_block_ticket(TICKET_ADAM, TICKET_ADAM_SUB, gridDim.x) && threadIdx.x == 0) t_dev[0] += 1;
 }
 extern "C" int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                                  float eps, float grad_scale, int32_t* t_dev, void* stream) {
@@ -1349,7 +1433,7 @@ __global__ void __launch_bounds__(256) random_normal_kernel(uint64_t seed, uint6
       if (4 * i + e < n) out[4 * i + e] = from_f32<T>(z[e]);
   }
   // device-counter form: the draw is counted by the block that finishes last (every block read the counter at its start)
-  if (draw_dev && last_block_ticket(TICKET_RNG, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
+  if (draw_dev && last_block_ticket(TICKET_RNG, TICKET_RNG_SUB, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
 }
 extern "C" int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, void* out,
                                  void* stream) {
@@ -1383,7 +1467,7 @@ __global__ void __launch_bounds__(256) random_uniform_kernel(uint64_t seed, uint
     for (int e = 0; e < 4; ++e)
       if (4 * i + e < n) out[4 * i + e] = u01(ph.c[e]);
   }
-  if (draw_dev && last_block_ticket(TICKET_RNG, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
+  if (draw_dev && last_block_ticket(TICKET_RNG, TICKET_RNG_SUB, gridDim.x) && threadIdx.x == 0) draw_dev[0] += 1;
 }
 extern "C" int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out, void* stream) {
   TDG_CHECK_ARG(out && n > 0, "tdg_random_uniform_f32: bad argument");
