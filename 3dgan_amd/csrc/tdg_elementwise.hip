@@ -818,9 +818,32 @@ __global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict_
                                                            float* __restrict__ acc, float beta) {
   __shared__ float sh[4];
   float s = 0.f;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const float v = to_f32<T>(x[i]);
-    s += v * v;
+  constexpr int VW = 16 / (int)sizeof(T);
+  if ((((uintptr_t)x) & 15) == 0) {                    // 16 bytes per access (scalar 2-byte loads ran at 0.4 TB/s)
+    const size_t nv = n / VW;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < nv; i += (size_t)gridDim.x * 256) {
+      float v[VW];
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 t = reinterpret_cast<const bf16x8*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+      } else {
+        const f32x4 t = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = t[e];
+      }
+#pragma unroll
+      for (int e = 0; e < VW; ++e) s += v[e] * v[e];
+    }
+    for (size_t i = nv * VW + blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      const float v = to_f32<T>(x[i]);
+      s += v * v;
+    }
+  } else {
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+      const float v = to_f32<T>(x[i]);
+      s += v * v;
+    }
   }
   s = block_sum256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
