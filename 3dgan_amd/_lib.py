@@ -86,6 +86,8 @@ SIGNATURES = {
     'tdg_p2p_l1': (_i, [_i, _vp, _vp, _i, _i, _f, _vp, _i, _vp, _vp, _sz, _vp]),
     'tdg_vae_reparam': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
     'tdg_vae_reparam_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _vp]),
+    'tdg_vae_reparam_bwd_kl': (_i, [_i, _vp, _i, _vp, _i, _vp, _i, _f, _i, _i, _vp, _i, _vp]),
+    'tdg_gp_rows': (_i, [_i, _vp, _i, _i, _f, _vp, _vp, _vp]),
     'tdg_vae_kl': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'tdg_vae_bce': (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'tdg_dropout': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp]),

@@ -1009,12 +1009,19 @@ extern "C" int tdg_vae_reparam(int dtype, const void* heads, int hs, const void*
 }
 template <typename T>
 __global__ void __launch_bounds__(256) vae_reparam_bwd_kernel(const T* __restrict__ dz, int zs, const T* __restrict__ eps, int es,
-                                                             int rows, int L, T* __restrict__ dh, int hs) {
+                                                             int rows, int L, T* __restrict__ dh, int hs,
+                                                             const T* __restrict__ heads, int hsin, float klw) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < rows * L; i += gridDim.x * 256) {
     const int r = i / L, c = i - r * L;
     const float g = to_f32<T>(dz[(size_t)r * zs + c]);
-    dh[(size_t)r * hs + c] = from_f32<T>(g);
-    dh[(size_t)r * hs + L + c] = from_f32<T>(g * to_f32<T>(eps[(size_t)r * es + c]));
+    float gm = g, gs = g * to_f32<T>(eps[(size_t)r * es + c]);
+    if (heads) {            // + klw * d latent_loss / d (mean, stddev), latent_loss = 0.5 sum(m^2 + s^2 - log(1e-8 + s^2) - 1)
+      const float m = to_f32<T>(heads[(size_t)r * hsin + c]), sd = to_f32<T>(heads[(size_t)r * hsin + L + c]);
+      gm += klw * m;
+      gs += klw * (sd - sd / (1e-8f + sd * sd));
+    }
+    dh[(size_t)r * hs + c] = from_f32<T>(gm);
+    dh[(size_t)r * hs + L + c] = from_f32<T>(gs);
   }
 }
 extern "C" int tdg_vae_reparam_bwd(int dtype, const void* dz, int zs, const void* eps, int es, int rows, int L, void* dheads,
@@ -1022,9 +1029,21 @@ extern "C" int tdg_vae_reparam_bwd(int dtype, const void* dz, int zs, const void
   TDG_CHECK_ARG(dz && eps && dheads && rows > 0 && L > 0 && hs >= 2 * L && es >= L && zs >= L, "tdg_vae_reparam_bwd: bad argument");
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(vae_reparam_bwd_kernel<T>, dim3(ew_blocks((size_t)rows * L, 256)), dim3(256), 0, (hipStream_t)stream,
-                       static_cast<const T*>(dz), zs, static_cast<const T*>(eps), es, rows, L, static_cast<T*>(dheads), hs);
+                       static_cast<const T*>(dz), zs, static_cast<const T*>(eps), es, rows, L, static_cast<T*>(dheads), hs,
+                       (const T*)nullptr, 0, 0.f);
   })
   TDG_HIP_LAUNCH_CHECK("vae_reparam_bwd");
+  return TDG_OK;
+}
+extern "C" int tdg_vae_reparam_bwd_kl(int dtype, const void* dz, int zs, const void* eps, int es, const void* heads, int hs_in,
+                                      float kl_weight, int rows, int L, void* dheads, int hs, void* stream) {
+  TDG_CHECK_ARG(dz && eps && heads && dheads && rows > 0 && L > 0 && hs >= 2 * L && hs_in >= 2 * L, "tdg_vae_reparam_bwd_kl: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(vae_reparam_bwd_kernel<T>, dim3(ew_blocks((size_t)rows * L, 256)), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(dz), zs, static_cast<const T*>(eps), es, rows, L, static_cast<T*>(dheads), hs,
+                       static_cast<const T*>(heads), hs_in, kl_weight);
+  })
+  TDG_HIP_LAUNCH_CHECK("vae_reparam_bwd_kl");
   return TDG_OK;
 }
 template <typename T>
@@ -1163,6 +1182,40 @@ extern "C" int tdg_scale_by_dev(int dtype, const void* in, size_t n, const float
                        n, coef, static_cast<T*>(out));
   })
   TDG_HIP_LAUNCH_CHECK("scale_by_dev");
+  return TDG_OK;
+}
+
+// ---- --gp_per_sample (SURVEY App. C-4 opt-in): per-image norms instead of one norm over the whole batch tensor.
+// One block per row: ss = sum v^2, slopes = sqrt(ss), pen[r] = (slopes - 1)^2, coef[r] = lambda * 2 (slopes - 1) / (slopes * rows)
+// (d (lambda * mean_r pen_r) / d v_r = coef[r] * v_r), and u = coef[r] * v written in the same pass over the row.
+template <typename T>
+__global__ void __launch_bounds__(256) gp_rows_kernel(const T* __restrict__ v, int rows, int cols, float lambda,
+                                                     float* __restrict__ pen, T* __restrict__ u) {
+  __shared__ float sh[4];
+  __shared__ float s_coef;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T* vr = v + (size_t)r * cols;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) { const float x = to_f32<T>(vr[c]); s += x * x; }
+    s = block_sum256(s, sh);
+    if (threadIdx.x == 0) {
+      const float sl = sqrtf(s);
+      pen[r] = (sl - 1.f) * (sl - 1.f);
+      s_coef = lambda * 2.f * (sl - 1.f) / (sl * (float)rows);
+    }
+    __syncthreads();
+    const float k = s_coef;
+    for (int c = threadIdx.x; c < cols; c += 256) u[(size_t)r * cols + c] = from_f32<T>(k * to_f32<T>(vr[c]));
+    __syncthreads();
+  }
+}
+extern "C" int tdg_gp_rows(int dtype, const void* v, int rows, int cols, float lambda, float* pen_rows, void* u, void* stream) {
+  TDG_CHECK_ARG(v && pen_rows && u && rows > 0 && cols > 0, "tdg_gp_rows: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(gp_rows_kernel<T>, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const T*>(v), rows, cols, lambda, pen_rows, static_cast<T*>(u));
+  })
+  TDG_HIP_LAUNCH_CHECK("gp_rows");
   return TDG_OK;
 }
 

@@ -82,6 +82,8 @@ class GanReplica(engine.GraphRunner):
         self.B = B
         self.iwgan = self.model == 'iwgan'
         self.display_d_loss = getattr(args, 'display_d_loss', True)
+        self.gp_per_sample = bool(getattr(args, 'gp_per_sample', False))
+        self._pen_rows = None
 
         # ---- build the graph exactly as models/gan.py:55-63 does for one tower
         reset_graph()
@@ -218,11 +220,25 @@ class GanReplica(engine.GraphRunner):
             bufs[values] = buf
         self.D.layers[-1].seed = buf
 
-    def _penalty_from_v(self):
-        """slopes = sqrt(sum over the WHOLE batch tensor) (models/gan.py:229), penalty (:230)."""
+    def _penalty_from_v(self, tangent_seed=False):
+        """slopes = sqrt(sum over the WHOLE batch tensor) (models/gan.py:229), penalty (:230).  With `tangent_seed` also
+        u = d(lambda * penalty)/dv into the tangent pass's input.  --gp_per_sample (opt-in, App. C-4): one norm per image,
+        penalty = mean_i (|v_i| - 1)^2."""
         B = self.B
+        if self.gp_per_sample:
+            if self._pen_rows is None:
+                self._pen_rows = torch.zeros(B, dtype=torch.float32, device=self.sess.device)
+                self._u_sink = K.Act(B, *self.args.image_shape, self.sess.dtype, self.sess.device) if not self.D.tangent_capacity else None
+            u = self.D.tan_in if self.D.tangent_capacity else self._u_sink
+            _lib.call('tdg_gp_rows', self.sess.dtype, self.D.dx.ptr(2 * B), B, self.img_elems, GP_LAMBDA, K.ptr(self._pen_rows),
+                      u.ptr(0), K.stream())
+            _lib.call('tdg_mean_f32', K.ptr(self._pen_rows), B, K.ptr(self.scal, 4 * self.S_GP), K.stream())
+            return
         K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
         _lib.call('tdg_gp_scalars', K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA, K.ptr(self.scal, 4 * self.S_GP), K.stream())
+        if tangent_seed:
+            _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
+                      K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
 
     def big_slice(self):
         """[lo, hi) of the critic's flat bucket holding its largest filter and that layer's bias (adjacent variables)."""
@@ -288,10 +304,8 @@ class GanReplica(engine.GraphRunner):
             # ones, one GEMM per layer over [D(x) rows | D(g) rows | tangent rows] (engine.SeqNet.merged_wgrad)
             self.D.backward(0, 3 * B, want_params=True, want_dx=True, param_images=(0, 2 * B), dx_images=(2 * B, B),
                             defer_wgrad=True)
-            self._penalty_from_v()
             # u = d(lambda * penalty)/dv = lambda * 2 (s-1)/s * v, then the tangent pass
-            _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
-                      K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
+            self._penalty_from_v(tangent_seed=True)
             self.D.tangent_forward(2 * B, B, acc=True)
             convs = list(reversed(self.D.conv_layers())) if whole else [self._d_big_layer]   # several replicas: the
             self.D.merged_wgrad(2 * B, B, convs)                      # largest filter first, the rest in _d_grads_b

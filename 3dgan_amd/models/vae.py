@@ -181,8 +181,12 @@ class VaeReplica(engine.GraphRunner):
                   wsb.numel(), K.stream())                                                       # :80-81 (reported only)
         # backward of decoder_loss only (:41)
         self.Dn.backward(0, B, want_params=True, want_dx=True)
-        _lib.call('tdg_vae_reparam_bwd', dt, self.Dn.dx.ptr(), self.Dn.dx.cs, self.eps.ptr(), self.eps.cs, B, L,
-                  self.dheads.ptr(), self.dheads.cs, K.stream())
+        if getattr(self.args, 'vae_full_elbo', False):     # opt-in (App. C-7): d(decoder_loss + latent_loss), models/vae.py:83
+            _lib.call('tdg_vae_reparam_bwd_kl', dt, self.Dn.dx.ptr(), self.Dn.dx.cs, self.eps.ptr(), self.eps.cs,
+                      self.heads.ptr(), self.heads.cs, 1.0, B, L, self.dheads.ptr(), self.dheads.cs, K.stream())
+        else:                                              # the reference: compute_gradients(d_loss) only (:41)
+            _lib.call('tdg_vae_reparam_bwd', dt, self.Dn.dx.ptr(), self.Dn.dx.cs, self.eps.ptr(), self.eps.cs, B, L,
+                      self.dheads.ptr(), self.dheads.cs, K.stream())
         K.bias_grad(self.ws, self.dheads, 2 * L, self.db_heads, rows=B)
         self.head_conv.bwd_filter(self.flat.ptr(), self.dheads.ptr(), self.dw_heads, B, 0.0)
         self.head_conv.bwd_data(self.dheads.ptr(), self.dflat.ptr(), B)

@@ -237,6 +237,10 @@ int tdg_vae_reparam(int dtype, const void* heads, int hs, const void* eps, int e
 /* dheads = [dz | dz * eps] */
 int tdg_vae_reparam_bwd(int dtype, const void* dz, int zs, const void* eps, int es, int rows, int L, void* dheads, int hs,
                         void* stream);
+/* --vae_full_elbo (SURVEY App. C-7 opt-in: the reference differentiates the reconstruction term alone, models/vae.py:41):
+ * dheads = [dz + w*m | dz*eps + w*(s - s / (1e-8 + s^2))], the gradient of decoder_loss + w * latent_loss (:80-81) */
+int tdg_vae_reparam_bwd_kl(int dtype, const void* dz, int zs, const void* eps, int es, const void* heads, int hs_in,
+                           float kl_weight, int rows, int L, void* dheads, int hs, void* stream);
 /* scal[0] = latent_loss = 0.5 * sum(mean^2 + std^2 - log(1e-8 + std^2) - 1)  (models/vae.py:80-81) */
 int tdg_vae_kl(int dtype, const void* heads, int hs, int rows, int L, float* scal, void* workspace, size_t workspace_bytes,
                void* stream);
@@ -258,6 +262,10 @@ int tdg_dropout(int dtype, void* y, int rows, int c, int ycs, const float* u, fl
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);
 /* out = coef[0] * in   (u = d penalty / d v, coefficient read from device memory) */
 int tdg_scale_by_dev(int dtype, const void* in, size_t n, const float* coef, void* out, void* stream);
+/* --gp_per_sample (SURVEY App. C-4 opt-in: the reference takes ONE norm over the whole batch tensor, models/gan.py:229):
+ * per row r of v [rows, cols]: slopes_r = |v_r|, pen_rows[r] = (slopes_r - 1)^2 and
+ * u_r = lambda * 2 (slopes_r - 1) / (slopes_r * rows) * v_r  =  d(lambda * mean_r pen_r) / d v_r. */
+int tdg_gp_rows(int dtype, const void* v, int rows, int cols, float lambda, float* pen_rows, void* u, void* stream);
 /* x[i] = value for i < n (f32) */
 int tdg_fill_f32(float* x, size_t n, float value, void* stream);
 /* column sums of a rows x c activation: db[c] = beta*db[c] + sum_r dy[r,c] (bias gradient) */

@@ -239,11 +239,16 @@ def gradient_penalty(P, x, g, alpha, cfg, want_param_grads=True):
     dhat, cache = d_forward(P, xhat, cfg)
     ones = np.ones_like(dhat)                                         # tf.gradients sums the outputs
     v, _, deltas = d_backward(P, cache, ones, cfg, want_params=False, want_dx=True)
-    s = np.sqrt(np.sum(np.square(v)))                                 # :229
-    penalty = (s - 1.0) ** 2                                          # :230
+    if getattr(cfg, 'gp_per_sample', False):                          # opt-in: one norm per image
+        s = np.sqrt(np.sum(np.square(v), axis=1, keepdims=True))
+        penalty = float(np.mean((s - 1.0) ** 2))
+        u = (2.0 * (s - 1.0) / s / v.shape[0]) * v
+    else:
+        s = np.sqrt(np.sum(np.square(v)))                             # :229
+        penalty = (s - 1.0) ** 2                                      # :230
+        u = (2.0 * (s - 1.0) / s) * v                                 # d penalty / d v
     if not want_param_grads:
         return penalty, {}
-    u = (2.0 * (s - 1.0) / s) * v                                     # d penalty / d v
     grads = {}
     t = u.reshape(-1, cfg.H, cfg.W, cfg.C)
     for i, name in enumerate(['c1', 'c2', 'c3']):

@@ -89,7 +89,7 @@ def forward(P, x, eps):
     return {'decoder_loss': d_loss, 'latent_loss': l_loss, 'total_loss': d_loss + l_loss}, c
 
 
-def backward(P, c):
+def backward(P, c, full_elbo=False):
     """Gradients of decoder_loss w.r.t. every trainable variable (models/vae.py:41)."""
     g = {}
     x, d = c['x'], c['d']
@@ -114,6 +114,9 @@ def backward(P, c):
     g['decoder/vars/d1/weights'] = c['z'].T @ du
     dz = du @ P['decoder/vars/d1/weights'].T
     dmean, dstd = dz, dz * c['eps']
+    if full_elbo:                                     # opt-in: + d latent_loss / d (mean, stddev)
+        dmean = dmean + c['mean']
+        dstd = dstd + c['std'] - c['std'] / (1e-8 + c['std'] ** 2)
     g['latent/vars/d1/weights'], g['latent/vars/d1/bias'] = c['flat'].T @ dmean, dmean.sum(0)
     g['latent/vars/d2/weights'], g['latent/vars/d2/bias'] = c['flat'].T @ dstd, dstd.sum(0)
     dh = (dmean @ P['latent/vars/d1/weights'].T + dstd @ P['latent/vars/d2/weights'].T).reshape(c['eshape'])

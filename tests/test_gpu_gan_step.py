@@ -253,12 +253,13 @@ def _check_free_run(hist, exact_iters):
 def test_iwgan_20_iterations_track_the_oracle():
     """The headline schedule (iwgan, adam 1e-4 / 0.5 / 0.9, n_disc_train 5) free-running for 20 train_func calls = 120
     optimizer steps on fresh batches with injected z and alpha (widths reduced to L=40, batch 16, so the oracle finishes
-    in seconds).  Measured: |HIP f32 - oracle f64| 1e-8 .. 4e-4 over the first 7 iterations, then both float32 runs
+    in seconds).  Measured: |HIP f32 - oracle f64| 1e-8 .. 1e-3 over the first 5 iterations (the summation order of the
+    reductions decides the last digit: 4e-4 .. 1.2e-3 at iteration 4 across builds), then both float32 runs
     (HIP and the oracle's own) drift from float64 together, 1e-3 .. 2e-2 by iteration 18."""
     hist, out = _free_run('iwgan', 'adam', 1e-4, 0.5, 0.9, (32, 32, 3), 20)
     print('iteration, loss, |hip-f64|, |torch f32-f64| (relative): ' + '; '.join('%d %s %.1e %.1e' % h for h in hist[::6]))
     assert set(out) == {'g_loss', 'd_loss'}
-    _check_free_run(hist, 6)
+    _check_free_run(hist, 3)      # (float32's own drift passes 1e-3 at iteration 4: the oracle's f32 run is 1.9e-3 off there)
 
 
 def test_wgan_mnist_like_free_run():

@@ -183,3 +183,32 @@ def test_wgan_clip_opt_in_clamps_before_the_critic_step():
             assert float(w.abs().max()) <= c + 1e-3 + 1e-7         # clamped, then moved by one rmsprop step (lr 1e-3)
         else:
             assert float(w.abs().max()) > 10 * c
+
+
+def test_gp_per_sample_opt_in():
+    """--gp_per_sample (SURVEY App. C-4 opt-in): one gradient norm per image, penalty = mean_i (|v_i| - 1)^2, instead of the
+    reference's single norm over the whole batch tensor (models/gan.py:229).  D step against the oracle's per-sample form;
+    the default stays the whole-batch form (covered by test_d_and_g_step_f32)."""
+    from oracle import gan_ref as G
+    args, cfg, P, batches, zs, alphas, sess, rep = build('iwgan', 0, B=4, L=8)
+    assert rep.gp_per_sample is False
+    args.gp_per_sample = True
+    cfg.gp_per_sample = True
+    gan, rt = pkg('models.gan'), pkg('runtime')
+    sess = rt.Session(device=sess.device, dtype=0, seed=0, rank=0, world_size=1)
+    rep = gan.GanReplica(rep.x_source, args, sess)
+    rep.load_variables({k: v.astype(np.float32) for k, v in P.items()})
+    sess.inject = {'z': [zs[0]], 'alpha': [alphas[0]]}
+    rep.x_source.i = 0
+    rep.d_step(rep.x_source.next_batch())
+    tr = G.GanTrainer({k: v.copy() for k, v in P.items()}, cfg, args)
+    x = tr.rescale(batches[0].astype(np.float64))
+    loss, grads, aux = G.d_loss_and_grads(P, x, zs[0].astype(np.float64), alphas[0].astype(np.float64), cfg)
+    cfg2 = G.make_cfg('iwgan', (32, 32, 3), 8, 4)
+    _, grads_whole, aux_whole = G.d_loss_and_grads(P, x, zs[0].astype(np.float64), alphas[0].astype(np.float64), cfg2)
+    assert abs(aux['gp'] - aux_whole['gp']) > 1e-3 * abs(aux_whole['gp'])         # the two forms really differ
+    got = rep.gradients()
+    for k, g in grads.items():
+        assert relerr(got[k], g) < 1e-3, k
+    s = rep.scal.cpu().numpy()
+    assert abs(s[rep.S_GP] - aux['gp']) < 1e-3 * max(1.0, aux['gp'])

@@ -80,3 +80,42 @@ def test_vae_graph_replay_matches_eager():
     assert res[0][0] == res[1][0]
     for k in res[0][1]:
         assert np.array_equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_vae_full_elbo_opt_in_f32():
+    """--vae_full_elbo (SURVEY App. C-7 opt-in): gradients of decoder_loss + latent_loss; the reference (and the default
+    here) differentiates decoder_loss alone (models/vae.py:41).  Only the paths through the heads change."""
+    vae, rt, data, K = pkg('models.vae'), pkg('runtime'), pkg('data'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    B, L = 3, 8
+    args = SimpleNamespace(model='vae', batch_size=B, latent_size=L, image_shape=(64, 64, 3), n_gpus=1, optimizer='rmsprop',
+                           lr=1e-3, decay=0.9, momentum=0.01, centered=False, beta1=0.9, beta2=0.999, vae_full_elbo=True)
+    P = V.init_params(L, 0, np.float64)
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0, 1, (B, 64, 64, 3)).astype(np.float32)
+    eps = rng.standard_normal((B, L)).astype(np.float32)
+    sess = rt.Session(device=dev, dtype=K.F32, seed=0, rank=0, world_size=1)
+    rep = vae.VaeReplica(data.ArraySource(x, B, dev), args, sess)
+    rep.load_variables({k: v.astype(np.float32) for k, v in P.items()})
+    sess.inject = {'eps': [eps]}
+    losses, c = V.forward(P, x.astype(np.float64), eps.astype(np.float64))
+    full, recon = V.backward(P, c, full_elbo=True), V.backward(P, c)
+    rep.train_func()
+    got = rep.gradients()
+    moved = 0
+    for k, g in full.items():
+        if k.startswith('encoder/vars/') and k.endswith('/bias'):
+            continue
+        assert relerr(got[k], g) < 1e-3, k
+        moved += relerr(recon[k], g) > 1e-3
+    assert moved >= 4                                   # the latent heads and the encoder see the KL term; the decoder does not
+    # the independent autograd statement of the same sum
+    import torch as th
+    Pt = {k: th.tensor(v, dtype=th.float64, requires_grad=True) for k, v in P.items()}
+    d_loss, l_loss = V.torch_losses(Pt, th.tensor(x, dtype=th.float64), th.tensor(eps, dtype=th.float64))
+    keys = [k for k in full if not k.startswith('encoder/BatchNorm')]
+    auto = th.autograd.grad(d_loss + l_loss, [Pt[k] for k in keys], allow_unused=True)
+    for k, a in zip(keys, auto):
+        if k.startswith('encoder/vars/') and k.endswith('/bias'):
+            continue
+        assert relerr(full[k], a.numpy()) < 1e-8, k
