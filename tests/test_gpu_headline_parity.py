@@ -271,3 +271,45 @@ def test_headline_step_bf16_vs_f32():
     for k, v in worst.items():
         lim = next(b for name, b in BF16_REL_L2.items() if name in k)
         assert v < lim, (k, v, lim)
+
+
+@pytest.mark.parametrize('dtype', [0, 1], ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', HEADLINE_CONVS, ids=lambda c: c[0])
+def test_headline_conv_adjoint_and_bilinear_identities(case, dtype):
+    """Size-independent properties of the three GEMM forms at the FULL headline size (1536 images), no oracle needed:
+      <dy, conv(x; W)>  =  <conv_backprop_input(dy; W), x>  =  <conv_backprop_filter(x, dy), W>
+    (the three are one trilinear form in x, W, dy).  All of them are accumulated in float64 on the device from the HIP
+    outputs; f32: 2e-4 (exact-f32 MFMA, summation order only), bf16: 6e-3 (the outputs of the first two forms are stored
+    as bf16: 2^-9 per element, averaged over ~1e7 terms of mixed sign)."""
+    K = pkg('kernels')
+    name, h, w, cin, cout = case
+    n, k, s = N_HEADLINE, 5, 2
+    dev = torch.device('cuda:0')
+    g = torch.Generator(device='cpu').manual_seed(cin)
+    oh, pt, _ = T.same_pad(h, k, s)
+    ow, pl, _ = T.same_pad(w, k, s)
+    big, small = K.Act(n, h, w, cin, dtype, dev), K.Act(n, oh, ow, cout, dtype, dev)
+    conv = K.Conv(big, small, k, k, s, pt, pl)
+    td = K.TORCH_DTYPE[dtype]
+    x = torch.randn(n, h, w, cin, generator=g).to(dev).to(td)
+    dy = torch.randn(n, oh, ow, cout, generator=g).to(dev).to(td)
+    W = (torch.randn(k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5).to(dev)
+    if dtype == 1:
+        W = W.bfloat16().float()                        # the packed operand is the bf16 rounding of the master
+    assert big.cs == cin and small.cs == cout           # unpadded layouts: the buffers ARE the tensors
+    conv.pack(W)
+    big.buf.copy_(x.reshape(-1))
+    y = small.like()
+    conv.fwd(big.ptr(), y.ptr(), n)
+    a = float((y.buf.double() * dy.reshape(-1).double()).sum())
+    small.buf.copy_(dy.reshape(-1))
+    dx = big.like()
+    conv.bwd_data(small.ptr(), dx.ptr(), n)
+    b = float((dx.buf.double() * x.reshape(-1).double()).sum())
+    dw = torch.zeros(k, k, cin, cout, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n)
+    c = float((dw.double() * W.double()).sum())
+    scale = float(y.buf.double().abs().mean() * dy.double().abs().mean()) * y.buf.numel() ** 0.5      # size of a random-sign sum
+    tol = (2e-4 if dtype == 0 else 6e-3) * max(abs(c), scale)
+    print('%s %s: <dy,conv x> %.6e  <convT dy,x> %.6e  <dW,W> %.6e' % (name, 'bf16' if dtype else 'f32', a, b, c))
+    assert abs(a - c) < tol and abs(b - c) < tol, (a, b, c, tol)
