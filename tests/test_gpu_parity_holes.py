@@ -212,3 +212,35 @@ def test_gp_per_sample_opt_in():
         assert relerr(got[k], g) < 1e-3, k
     s = rep.scal.cpu().numpy()
     assert abs(s[rep.S_GP] - aux['gp']) < 1e-3 * max(1.0, aux['gp'])
+
+
+def test_epoch_summaries_from_a_live_replica(tmp_path):
+    """Summaries-lite on the GPU path (models/gan.py:93-107): `replica.samples(64)` returns the first 64 images of the
+    staged real batch and of a fresh generator pass in [-1, 1]; `write_epoch` lays them out as the 8 x 8 `inputs` / `fake`
+    montages (ops/summaries.py:97-124) and the PNG files decode back to exactly those pixels."""
+    gan, rt, data, S, png = pkg('models.gan'), pkg('runtime'), pkg('data'), pkg('summaries'), pkg('png')
+    dev = torch.device('cuda:0')
+    B, L, shape = 64, 16, (32, 32, 3)
+    args = SimpleNamespace(model='iwgan', batch_size=B, latent_size=L, image_shape=shape, n_gpus=1, optimizer='adam', lr=1e-4,
+                           beta1=0.5, beta2=0.9, decay=0.9, momentum=0.01, centered=False, n_disc_train=1, display_d_loss=True)
+    sess = rt.Session(device=dev, dtype=1, seed=2, rank=0, world_size=1)
+    src = data.SyntheticSource(4 * B, shape, B, dev, seed=9)
+    rep = gan.GanReplica(src, args, sess)
+    status = rep.train_func()
+    real, fake = rep.samples(64)
+    assert real.shape == fake.shape == (64, 32, 32, 3)
+    assert real.min() >= -1.0 and real.max() <= 1.0 and np.abs(fake).max() <= 1.0 and np.abs(fake).max() > 0
+    staged = rep.x_stage.cpu().numpy()                            # the batch the last step consumed, in [0, 1]
+    assert np.abs(real - (2 * staged - 1)).max() < 1e-2           # bf16 storage of 2 (x - 0.5)
+    files = S.write_epoch(str(tmp_path), 1, status, real, fake, 64)
+    assert [os.path.basename(f) for f in files] == ['losses.csv', 'montage-inputs-0001.png', 'montage-fake-0001.png']
+    with open(files[0]) as f:
+        header, row = f.read().strip().split('\\n')
+    assert header == 'epoch,d_loss,g_loss' and row.startswith('1,')
+    for path, t in ((files[1], real), (files[2], fake)):
+        img = png.decode(open(path, 'rb').read())
+        assert img.shape == (8 * 32, 8 * 32, 3)
+        want = np.clip(np.rint((t + 1.0) / 2.0 * 255.0), 0, 255).astype(np.uint8)
+        for j in (0, 3, 7):
+            for r in (0, 5):
+                assert np.array_equal(img[j * 32:(j + 1) * 32, r * 32:(r + 1) * 32], want[j * 8 + r])
