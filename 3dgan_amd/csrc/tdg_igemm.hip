@@ -1210,9 +1210,6 @@ __device__ __forceinline__ int wd_f(int row) { return (row & 3) | (((row >> 3) &
 // works this way (rows are contiguous); the gathered one when a step covers whole images (64 % (GH*GW) == 0: every
 // layer of the 32x32 / 64x64 GAN), FAST = true.  Otherwise (pix2pix, VAE: images larger than a step) the gathered
 // operand keeps the per-piece decomposition.
-struct WdDescs {
-  i32x4 a1, a2, g;
-};
 // A buffer window [p, p + rem) that moves by a constant per step; scalar registers only.  (Tensors are < 4 GB -- the C
 // ABI's byte counts are 32-bit -- so a non-negative rem fits num_records.)
 struct WdCursor {
@@ -1224,37 +1221,69 @@ struct WdCursor {
     return i32x4{(int)(unsigned)p, (int)(unsigned)(p >> 32), (int)r, 0x00020000};
   }
 };
-template <bool FAST>
+// MODE 0: per-piece decomposition of the gathered operand (any geometry).  MODE 1 ("FAST"): a step covers whole images
+// (64 % (GH*GW) == 0): constant lane offsets, moving descriptor.  MODE 2 ("RECT"): a step covers a rectangle of ONE image
+// -- 64 / GW whole rows (64 % GW == 0) or a 64-column piece of one row (GW % 64 == 0), images being multiples of 64 rows --
+// so a row's (y, x) is a lane constant plus the step's scalar corner (sa, sb): the descriptor moves to the corner
+// (minus a halo, so that taps above / left of it keep non-negative offsets) and the only per-piece vector work left is
+// the bounds test of the tap against the image (two adds, two compares, one select) instead of two divisions and six
+// multiplies.  pix2pix / VAE layers and the critic's c1.
+struct WdDescs {
+  i32x4 a1, a2, g;
+  int sa, sb;                                // MODE 2: sigma * (first row, first column) of the step's rectangle
+};
+#define WD_HALO 8
+template <int MODE>
 struct WdLoader {
+  static constexpr bool FAST = MODE == 1;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   unsigned long long baseA, baseA2, baseG;   // baseA2 = src2 - img_switch images: rows >= m_switch index it like baseA
   long long endA, endA2, endG;               // bytes from the base that rows < min(m_end, m_switch) / < m_end may touch
   long long stepA, stepG;                    // bytes per 64-row step (FAST: whole images)
   unsigned voA[4], voG[4];                   // per-lane byte offsets inside a step (OOB_OFFSET: padding)
-  i32x4 rA, rA2;                             // !FAST: whole-tensor descriptors
+  int ihl[4], iwl[4];                        // MODE 2: lane part of the tap's source row / column (huge: padding chunk)
+  i32x4 rA, rA2;                             // MODE 0: whole-tensor descriptors
+  unsigned long long src1, src2p;            // MODE 2: tensor bases and sizes
+  long long src1_bytes, src2_bytes;
   unsigned lds0;                             // LDS byte address of the ring
   int m_begin, m_switch, img_switch;         // rows >= m_switch gather from the second tensor (its image 0 = image img_switch)
   FastDiv fd_ghw, fd_gw;
-  int GHW, GW, SH, SW, Cs, sigma, m_end;
+  int GHW, GW, GH, SH, SW, Cs, sigma, m_end;
   int a_dh, a_dw, a_koff, a_kok, hrow;
   int Ibase;                        // b0 | b2 << 2 | b4 << 4
   // cursors of the three operands at the split's first step / their descriptors / one step forward
   struct Cursors {
     WdCursor a1, a2, g;
+    int nb, a0, b0;                 // MODE 2: image and corner (grid units) of the step
   };
   __device__ __forceinline__ Cursors begin() const {
     Cursors c;
     c.a1.p = baseA; c.a1.rem = endA;
     c.a2.p = baseA2; c.a2.rem = endA2;
     c.g.p = baseG; c.g.rem = endG;
+    c.nb = m_begin / GHW;
+    const int rem = m_begin - c.nb * GHW;
+    c.a0 = rem / GW;
+    c.b0 = rem - c.a0 * GW;
     return c;
   }
   __device__ __forceinline__ WdDescs descs(const Cursors& c) const {
     WdDescs d;
     d.g = c.g.desc();
-    if constexpr (FAST) {
+    d.sa = d.sb = 0;
+    if constexpr (MODE == 1) {
       d.a1 = c.a1.desc();
       d.a2 = c.a2.desc();
+    } else if constexpr (MODE == 2) {
+      const bool second = c.nb >= img_switch;
+      const long long e = ((long long)(second ? c.nb - img_switch : c.nb) * SH * SW + (long long)(c.a0 * sigma) * SW + c.b0 * sigma -
+                           (WD_HALO * SW + WD_HALO)) * Cs * 2;                                   // bytes; may be < 0 at the first rows
+      WdCursor w;
+      w.p = (second ? src2p : src1) + (unsigned long long)e;
+      w.rem = (second ? src2_bytes : src1_bytes) - e;
+      d.a1 = d.a2 = w.desc();
+      d.sa = c.a0 * sigma;
+      d.sb = c.b0 * sigma;
     } else {
       d.a1 = rA;
       d.a2 = rA2;
@@ -1263,9 +1292,16 @@ struct WdLoader {
   }
   __device__ __forceinline__ void advance(Cursors& c) const {
     c.g.advance(stepG);
-    if constexpr (FAST) {
+    if constexpr (MODE == 1) {
       c.a1.advance(stepA);
       c.a2.advance(stepA);
+    } else if constexpr (MODE == 2) {
+      c.b0 += GW < WD_MR ? GW : WD_MR;
+      if (c.b0 >= GW) {
+        c.b0 = 0;
+        c.a0 += GW < WD_MR ? WD_MR / GW : 1;
+        if (c.a0 >= GH) { c.a0 = 0; c.nb += 1; }
+      }
     }
   }
   template <int P>
@@ -1274,6 +1310,12 @@ struct WdLoader {
     constexpr int SLABB = WD_MR * WD_ROWB;
     const int I = Ibase | ((j & 1) << 1) | ((j >> 1) << 3);
     if constexpr ((P & 1) == 0) {
+      if constexpr (MODE == 2) {
+        const int ih = d.sa + ihl[j], iw = d.sb + iwl[j];
+        const int ok = ((unsigned)ih < (unsigned)SH) & ((unsigned)iw < (unsigned)SW);
+        lds_dma_b128(d.a1, ok ? voA[j] : OOB_OFFSET, lds0 + (unsigned)(stage_off + I * 1024));
+        return;
+      }
       // wave-uniform (m_switch is even: both rows on one side); scalar, so the descriptor is picked by s_cselect
       const bool second = __builtin_amdgcn_readfirstlane((int)(mstep + 2 * I >= m_switch)) != 0;
       unsigned offa;
@@ -1322,8 +1364,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-template <int BN, bool FAST>
+template <int BN, int MODE>
 __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs args) {
+  constexpr bool FAST = MODE == 1;
   using T = bf16_t;
   constexpr int BKK = 256, VEC = 8;
   constexpr int TK = 4, TN = (BN / 16 + 1) / 2, TN1 = BN / 16 - TN;
@@ -1373,7 +1416,7 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
   const int g_n = n0 + lch * VEC;
   const bool g_nok = (lch * VEC < TN * 32) && (g_n < args.N);
 
-  WdLoader<FAST> ld;
+  WdLoader<MODE> ld;
   {
     const long long imgbytes = (long long)SH * SW * Cs * 2;
     const int m_sw = m_end < args.m_switch ? m_end : args.m_switch;
@@ -1392,7 +1435,9 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
   ld.m_begin = m_begin; ld.m_switch = args.m_switch; ld.img_switch = args.img_switch;
   ld.lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
   ld.fd_ghw = args.fd_ghw; ld.fd_gw = args.fd_gw;
-  ld.GHW = GHW; ld.GW = GW; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.m_end = m_end;
+  ld.GHW = GHW; ld.GW = GW; ld.GH = args.GH; ld.SH = SH; ld.SW = SW; ld.Cs = Cs; ld.sigma = sigma; ld.m_end = m_end;
+  ld.src1 = (unsigned long long)args.src; ld.src1_bytes = (long long)args.src_bytes;
+  ld.src2p = (unsigned long long)(args.src2 ? args.src2 : args.src); ld.src2_bytes = (long long)(args.src2 ? args.src2_bytes : args.src_bytes);
   ld.a_dh = a_dh; ld.a_dw = a_dw; ld.a_koff = a_koff; ld.a_kok = (int)a_kok; ld.hrow = hrow;
   ld.Ibase = b0 | (b2 << 2) | (b4 << 4);
 #pragma unroll
@@ -1409,9 +1454,15 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
       const bool ok = a_kok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
       const unsigned base = ((nb * (unsigned)SH + a * (unsigned)sigma) * (unsigned)SW + b * (unsigned)sigma) * (unsigned)Cs;
       ld.voA[j] = ok ? (base + (unsigned)a_koff) * 2u : OOB_OFFSET;
+    } else if constexpr (MODE == 2) {
+      const int a_l = GW < WD_MR ? ml / GW : 0, b_l = GW < WD_MR ? ml - (ml / GW) * GW : ml;
+      ld.ihl[j] = a_kok ? a_l * sigma + a_dh : 0x40000000;          // a padding chunk never passes the bounds test
+      ld.iwl[j] = b_l * sigma + a_dw;
+      ld.voA[j] = (unsigned)(((a_l * sigma + WD_HALO) * SW + b_l * sigma + WD_HALO) * Cs + a_koff) * 2u;
     } else {
       ld.voA[j] = 0;
     }
+    if constexpr (MODE != 2) { ld.ihl[j] = 0; ld.iwl[j] = 0; }
   }
 
   const int r16 = lane & 15, q = lane >> 4;
@@ -1475,7 +1526,7 @@ __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs ar
     };
     // prologue: step 0 into stage 0, its slice-0 fragments, and the first pieces of step 1
     WdDescs dn1;
-    typename WdLoader<FAST>::Cursors cur = ld.begin();
+    typename WdLoader<MODE>::Cursors cur = ld.begin();
     ld.all_pieces(ld.descs(cur), m_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the asm-issued LDS-DMA is not counted by the compiler
     __syncthreads();
@@ -2277,23 +2328,23 @@ int launch_wgrad_cfg(const WgArgs& a, bool veca, hipStream_t s) {
   return TDG_OK;
 }
 
-template <int BN, bool FAST>
+template <int BN, int MODE>
 int launch_wgrad_dma(WgArgs& a, hipStream_t s) {
   const size_t lds = 4 * (size_t)WD_MR * WD_ROWB + IG_MAX_TAPS * sizeof(int);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<BN, FAST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_wgrad_dma_kernel<BN, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   static char name[64] = "";
-  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d,%d>", BN, (int)FAST);
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_wgrad_dma_kernel<bf16,256,%d,%d>", BN, MODE);
   dim3 grid(a.ntiles_k * a.ntiles_n, 1, a.nsplit), block(512);
   tdg_note_kernel(name);
 #ifdef TDG_STAMPS
   a.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
 #endif
   tdg_timing_start(name, t_flops, s);
-  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN, FAST>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_wgrad_dma_kernel<BN, MODE>), grid, block, lds, s, a);
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_wgrad_dma");
   return TDG_OK;
@@ -2987,10 +3038,20 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
   for (int kh = 0; kh < d->kh; ++kh)
     for (int kw = 0; kw < d->kw; ++kw) a.tap[kh * d->kw + kw] = pack_tap(kh - d->pad_t, kw - d->pad_l);
   t_flops = conv_flops(d, n_images);
-  // a 64-row step of whole images: the gathered operand's offsets are per-lane constants (WdLoader)
-  const bool fast = WD_MR % (d->oh * d->ow) == 0 && !getenv("TDG_WDMA_SLOWA");
-  rc = dma ? (bn == 208 ? (fast ? launch_wgrad_dma<208, true>(a, (hipStream_t)stream) : launch_wgrad_dma<208, false>(a, (hipStream_t)stream))
-                        : (fast ? launch_wgrad_dma<128, true>(a, (hipStream_t)stream) : launch_wgrad_dma<128, false>(a, (hipStream_t)stream)))
+  // loader mode of the gathered operand (WdLoader): 1 = a 64-row step of whole images, 2 = a rectangle of one image
+  // (whole grid rows, or a 64-column piece of one), 0 = anything else.  TDG_WDMA_SLOWA (diagnostics) forces 0.
+  const int ghw = d->oh * d->ow;
+  int mode = 0;
+  if (WD_MR % ghw == 0) mode = 1;
+  else if (ghw % WD_MR == 0 && (d->ow % WD_MR == 0 || WD_MR % d->ow == 0) && a.m_switch % WD_MR == 0 &&
+           d->pad_t <= WD_HALO && d->pad_l <= WD_HALO) mode = 2;
+  if (getenv("TDG_WDMA_SLOWA")) mode = 0;
+  auto go = [&](auto bn_c) -> int {
+    constexpr int B = decltype(bn_c)::value;
+    return mode == 1 ? launch_wgrad_dma<B, 1>(a, (hipStream_t)stream)
+                     : (mode == 2 ? launch_wgrad_dma<B, 2>(a, (hipStream_t)stream) : launch_wgrad_dma<B, 0>(a, (hipStream_t)stream));
+  };
+  rc = dma ? (bn == 208 ? go(std::integral_constant<int, 208>{}) : go(std::integral_constant<int, 128>{}))
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
