@@ -28,7 +28,8 @@ class Epilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('leak', C.c_float),
                 ('mask_mode', C.c_int32), ('mask_src', C.c_void_p), ('accumulate', C.c_int32),
                 ('col_partial', C.c_void_p), ('col_partial_bytes', C.c_size_t), ('col_mode', C.c_int32),
-                ('col_images', C.c_int32), ('col_nblk_out', C.POINTER(C.c_int32))]
+                ('col_images', C.c_int32), ('col_nblk_out', C.POINTER(C.c_int32)),
+                ('splitk_ws', C.c_void_p), ('splitk_ws_bytes', C.c_size_t)]
 
 
 class PackJob(C.Structure):

@@ -39,6 +39,10 @@ struct IgArgs {
   float leak;
   int ntiles_n, ntiles_m_max, nclasses;
   int n_begin;           // first output column of this launch (a problem's columns may be split over launches)
+  // split-K (small-M problems that would leave most CUs idle): blockIdx.y = K split, f32 partial tiles go to
+  // slab[(split * nclasses + class) * slab_rows + m][N]; splitk_finish_kernel sums them and applies the epilogue
+  int ksplit, steps_per_split, slab_rows;
+  float* slab;
   float* col_partial;    // per row tile [2][N] column sums of the stored tile (TdgEpilogue.col_partial), or null
   int col_mode;          // TDG_COL_*
   int col_images;        // rows of images >= col_images do not count (0: all)

@@ -401,11 +401,13 @@ struct DmaLoader {
   // state of the step being loaded
   int dh, dw, t_ok;
   unsigned koff, kbyte;
+  int step0;                    // first K step of this workgroup's split (0 without split-K)
 
   // K chunk (step, lch) -> tap (th, tw) and 16-byte vector cv inside the tap's channels
   // (the tap's source offset comes from the class's tap table: the table's ORDER is the K order of the packed
   //  filter, which the host is free to choose -- see fwd_tap_order)
   __device__ __forceinline__ void prepare(int step) {
+    step += step0;
     const unsigned chunk = (unsigned)(step * 8 + lch);
     const unsigned t = fd_div(chunk, fd_cv);
     const int cv = (int)(chunk - t * (unsigned)CV);
@@ -535,6 +537,15 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
     return;
   }
   const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
+  if (args.ksplit > 1 && (int)blockIdx.y * args.steps_per_split >= cl.nsteps) {
+    // a class with fewer K steps than the largest: this split's partial tile is zeros
+    float* sl = args.slab + ((size_t)(blockIdx.y * args.nclasses + blockIdx.z) * args.slab_rows + m0) * args.N;
+    for (int i = tid; i < BM * BN; i += NTHR) {
+      const int r = i / BN, c = i - r * BN;
+      if (m0 + r < M && n0 + c < args.N) sl[(size_t)r * args.N + n0 + c] = 0.f;
+    }
+    return;
+  }
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const bool is_loader = !WS || wave >= CW, is_mma = !WS || wave < CW;   // wave-uniform
@@ -601,7 +612,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nsteps = cl.nsteps;
+  const int s0 = (int)blockIdx.y * args.steps_per_split;      // split-K: this workgroup's K steps [s0, s0 + nsteps)
+  const int nsteps = min(cl.nsteps - s0, args.steps_per_split);
+  ld.step0 = s0;
   if constexpr (NS == 2) {
     ld.prepare(0);
     ld.all_pieces(smem);
@@ -745,6 +758,30 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
   const float* bias = args.bias;
   const int act = args.act, mmode = args.mask_mode, accum = args.accumulate;
   const float leak = args.leak;
+
+  if constexpr (!WS) {
+    if (args.ksplit > 1) {                           // split-K: raw f32 partial tile; splitk_finish_kernel does the rest
+      float* sl = args.slab + ((size_t)(blockIdx.y * args.nclasses + blockIdx.z) * args.slab_rows) * N;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + (wn * TN + j) * 16 + q * 4;
+        if (j >= tnw || n >= N) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = m0 + wm * WMR + i * 16 + r16;
+          if (m >= M) continue;
+          if (n + 3 < N) {
+            *reinterpret_cast<f32x4*>(sl + (size_t)m * N + n) = acc[i][j];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < N) sl[(size_t)m * N + n + e] = acc[i][j][e];
+          }
+        }
+      }
+      return;
+    }
+  }
 
   if constexpr (sizeof(T) == 2) {
     // bf16: stage the tile through the (now idle) LDS ring so that global stores (and mask loads) are whole
@@ -937,6 +974,41 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
         }
       }
     }
+  }
+}
+
+// Second half of a split-K forward-type GEMM: out[pixel(m)][n] = epilogue(sum over splits of slab[split][class][m][n]).
+// One thread per (class, row, 4 columns); splits are added in ascending order (deterministic).
+template <typename T>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const IgArgs args) {
+  const int N = args.N, N4 = (N + 3) >> 2;
+  const int cls = blockIdx.z;
+  const IgClass& cl = args.cls[cls];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int m = (int)(idx / N4), n = (int)(idx - (long long)m * N4) * 4;
+  if (m >= cl.M) return;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ks = 0; ks < args.ksplit; ++ks) {
+    const float* sl = args.slab + ((size_t)(ks * args.nclasses + cls) * args.slab_rows + m) * N + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (n + e < N) v[e] += sl[e];
+  }
+  const unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
+  const unsigned rem = (unsigned)m - nb * (unsigned)(cl.GH * cl.GW);
+  const unsigned a = fd_div(rem, cl.fd_gw);
+  const unsigned b = rem - a * (unsigned)cl.GW;
+  const size_t p = ((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
+                    b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)args.Cso;
+  T* out = static_cast<T*>(args.out);
+  const T* msk = static_cast<const T*>(args.mask_src);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (n + e >= N) continue;
+    float x = apply_act(v[e] + (args.bias ? args.bias[n + e] : 0.f), args.act, args.leak);
+    if (args.accumulate) x += to_f32<T>(out[p + n + e]);
+    if (args.mask_mode != TDG_MASK_NONE) x *= mask_factor(to_f32<T>(msk[p + n + e]), args.mask_mode, args.leak);
+    out[p + n + e] = from_f32<T>(x);
   }
 }
 
@@ -2149,6 +2221,7 @@ namespace {
 
 thread_local double t_flops = 0.0;   // algorithmic FLOPs of the entry-point call being dispatched (for tdg_timing_*)
 thread_local const TdgEpilogue* t_col = nullptr;   // column-partial request of the call being dispatched (fill_epilogue)
+thread_local const TdgEpilogue* t_splitk = nullptr;   // epilogue carrying a split-K workspace (fill_epilogue)
 
 struct TileCfg { int bm, bn; };
 
@@ -2203,9 +2276,40 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   if (!name[0]) snprintf(name, sizeof(name), WS ? "igemm_fwd_dma_kernel<%s,%d,%d,%d,8,1>" : (NW == 8 ? "igemm_fwd_dma_kernel<%s,%d,%d,%d>" : "igemm_fwd_dma_kernel<%s,%d,%d,%d,4,0>"), sizeof(T) == 2 ? "bf16" : "f32", BM, BN, NS);
   tdg_note_kernel(name);
   const int n_end = n_begin + a.ntiles_n * BN < a.N ? n_begin + a.ntiles_n * BN : a.N;
-  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(64 * NW);
+  // split-K: a grid that leaves most of the chip idle (pix2pix's 1x1 ... 8x8 bottleneck layers: 4 - 32 workgroups, each
+  // walking 128 - 256 K steps) is cut along K into f32 partial tiles, finished by splitk_finish_kernel
+  a.ksplit = 1;
+  a.steps_per_split = 1 << 30;
+  a.slab = nullptr;
+  a.slab_rows = a.ntiles_m_max * BM;
+  int smax = 0;
+  for (int c = 0; c < a.nclasses; ++c) smax = a.cls[c].nsteps > smax ? a.cls[c].nsteps : smax;
+  const long long wgs = (long long)a.ntiles_n * a.ntiles_m_max * a.nclasses;
+  const int ks_force = getenv("TDG_KSPLIT") ? atoi(getenv("TDG_KSPLIT")) : 0;                  // diagnostics: 1 = never, n = n splits
+  if (!WS && t_splitk && t_splitk->splitk_ws && wgs <= 96 && smax >= 16 && n_begin == 0 && a.ntiles_n * BN >= a.N && ks_force != 1) {
+    int want = (int)(256 / wgs);
+    if (want > smax / 4) want = smax / 4;                    // >= 4 steps per split
+    if (ks_force > 1) want = ks_force;
+    const int per = tdg_ceil_div(smax, want);
+    const int nsplit = tdg_ceil_div(smax, per);
+    const size_t need = (size_t)nsplit * a.nclasses * a.slab_rows * a.N * sizeof(float);
+    if (nsplit > 1 && need <= t_splitk->splitk_ws_bytes) {
+      a.ksplit = nsplit;
+      a.steps_per_split = per;
+      a.slab = static_cast<float*>(t_splitk->splitk_ws);
+      a.col_partial = nullptr;                               // (the partial tiles are not the stored tile)
+      if (t_col) *t_col->col_nblk_out = 0;
+    }
+  }
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, a.ksplit, a.nclasses), block(64 * NW);
   tdg_timing_start(name, t_flops * (double)(n_end - n_begin) / (double)a.N, s);
   hipLaunchKernelGGL((igemm_fwd_dma_kernel<T, BM, BN, NS, NW, WS>), grid, block, lds, s, a);
+  if (a.ksplit > 1) {
+    int mmx = 0;
+    for (int c = 0; c < a.nclasses; ++c) mmx = a.cls[c].M > mmx ? a.cls[c].M : mmx;
+    const long long items = (long long)mmx * ((a.N + 3) / 4);
+    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)((items + 255) / 256), 1, a.nclasses), dim3(256), 0, s, a);
+  }
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_dma");
   return TDG_OK;
@@ -2268,12 +2372,10 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
       return launch_fwd_dma<T, 128, 208, 3>(a, mmax, s);
     }
     // 192-row tile, bf16, staged epilogue: the wave-specialised form (4 compute + 4 loader waves; measured +5 % on
-    // these launches inside the training step).  TDG_DMA_NW (diagnostics): 8 = every wave loads and computes,
-    // 4 = four such waves, one per SIMD (measured: -17 %)
+    // these launches inside the training step).  TDG_DMA_NW (diagnostics): 8 = every wave loads and computes
+    // (a four-wave form, one wave per SIMD, measured -17 %, is no longer instantiated)
     const char* nw_env = getenv("TDG_DMA_NW");
     const int nw192 = nw_env ? atoi(nw_env) : 44;
-    if constexpr (sizeof(T) == 2)
-      if (bm == 192 && nw192 == 4) return launch_fwd_dma<T, 192, 208, 3, 4>(a, mmax, s);
     if constexpr (sizeof(T) == 2)
       if (bm == 192 && nw192 == 44 && !a.accumulate && ring192 != 2) return launch_fwd_dma<T, 192, 208, 3, 8, 1>(a, mmax, s);
     if (bm == 192) return ring192 == 2 ? launch_fwd_dma<T, 192, 208, 2>(a, mmax, s) : launch_fwd_dma<T, 192, 208, 3>(a, mmax, s);
@@ -2735,6 +2837,10 @@ static void fill_epilogue(IgArgs& a, const TdgEpilogue* epi) {
   a.col_partial = nullptr;
   a.col_mode = TDG_COL_NONE;
   a.col_images = 0;
+  a.ksplit = 1;
+  a.steps_per_split = 1 << 30;
+  a.slab = nullptr;
+  t_splitk = (epi && epi->splitk_ws && epi->splitk_ws_bytes) ? epi : nullptr;
   t_col = nullptr;
   if (epi && epi->col_partial && epi->col_mode != TDG_COL_NONE && epi->col_nblk_out) {
     *epi->col_nblk_out = 0;

@@ -87,6 +87,18 @@ def conv_desc(big, small, kh, kw, stride, pad_t, pad_l):
                     kh, kw, stride, pad_t, pad_l, big.dtype)
 
 
+_SPLITK = {}
+
+
+def splitk_workspace(device):
+    """One scratch buffer per device for split-K partial tiles (TdgEpilogue.splitk_ws): 64 MB covers the widest small-M
+    layer (4096 rows x 1024 columns x 4 splits)."""
+    buf = _SPLITK.get(device)
+    if buf is None:
+        buf = _SPLITK[device] = torch.empty(64 << 20, dtype=torch.uint8, device=device)
+    return buf
+
+
 def epilogue(bias=None, act=ACT_NONE, leak=0.2, mask_mode=MASK_NONE, mask_src=None, accumulate=False):
     e = Epilogue()
     e.accumulate = 1 if accumulate else 0
@@ -219,13 +231,25 @@ class Conv:
         d = self.desc
         return '%s/%s/%dx%d_c%d_k%d' % (form, 'bf16' if d.dtype == BF16 else 'f32', d.kh, d.kw, d.c, d.k)
 
+    def _with_splitk(self, epi):
+        """Every forward-type launch offers the library the device's split-K scratch (it decides per launch)."""
+        if epi is None:
+            epi = epilogue()
+        ws = splitk_workspace(self.big.buf.device)
+        epi.splitk_ws, epi.splitk_ws_bytes = ws.data_ptr(), ws.numel()
+        return epi
+
     def fwd(self, x_ptr, y_ptr, n_images, epi=None):
+        epi = self._with_splitk(epi)
+
         def go():
             _lib.call('tdg_conv2d_fwd', C.byref(self.desc), n_images, x_ptr, ptr(self.w_fwd), y_ptr,
                       C.byref(epi) if epi is not None else None, stream())
         TIMER.wrap(self._tag('fwd'), self.flops(n_images), go) if TIMER is not None else go()
 
     def bwd_data(self, y_ptr, x_ptr, n_images, epi=None):
+        epi = self._with_splitk(epi)
+
         def go():
             _lib.call('tdg_conv2d_bwd_data', C.byref(self.desc), n_images, y_ptr, ptr(self.w_bwd), x_ptr,
                       C.byref(epi) if epi is not None else None, stream())

@@ -85,6 +85,11 @@ typedef struct TdgEpilogue {
   int32_t col_mode;         /* TDG_COL_*                                     */
   int32_t col_images;
   int32_t* col_nblk_out;
+  /* Optional scratch for split-K (caller-owned, like every buffer): a forward-type GEMM whose grid would leave most CUs
+   * idle (few output rows, long K: pix2pix's 1x1 ... 8x8 bottleneck layers) is cut along K into f32 partial tiles here
+   * and finished by a second kernel in a fixed order.  NULL: never split. */
+  void* splitk_ws;
+  size_t splitk_ws_bytes;
 } TdgEpilogue;
 enum { TDG_COL_NONE = 0, TDG_COL_SUM = 1, TDG_COL_BN = 2 };
 

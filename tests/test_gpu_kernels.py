@@ -155,8 +155,21 @@ def test_conv_lds_dma_variant(case, dtype, monkeypatch):
         monkeypatch.setenv('TDG_DMA', mode)
         test_conv_fwd_bwd(case, dtype)
     monkeypatch.setenv('TDG_DMA', '3')
-    for nw in ('8', '4'):                        # the 192-row tile's other wave layouts (default: wave-specialised)
+    for nw in ('8',):                            # the 192-row tile with every wave loading and computing (default: wave-specialised)
         monkeypatch.setenv('TDG_DMA_NW', nw)
+        test_conv_fwd_bwd(case, dtype)
+
+
+@pytest.mark.parametrize('dtype', [0, 1])
+@pytest.mark.parametrize('case', [(2, 8, 8, 200, 400, 5, 2), (2, 16, 16, 128, 256, 4, 2), (3, 4, 4, 512, 512, 4, 2)])
+def test_conv_split_k_small_m(case, dtype, monkeypatch):
+    """Small-M forward-type GEMMs (pix2pix's bottleneck layers: a handful of workgroups, each 32 - 128 K steps deep) are cut
+    along K into f32 partial tiles plus a finishing kernel: default split count, forced ragged counts, and never."""
+    for ks in (None, '3', '7', '1'):
+        if ks is None:
+            monkeypatch.delenv('TDG_KSPLIT', raising=False)
+        else:
+            monkeypatch.setenv('TDG_KSPLIT', ks)
         test_conv_fwd_bwd(case, dtype)
 
 

@@ -235,7 +235,7 @@ def test_epoch_summaries_from_a_live_replica(tmp_path):
     files = S.write_epoch(str(tmp_path), 1, status, real, fake, 64)
     assert [os.path.basename(f) for f in files] == ['losses.csv', 'montage-inputs-0001.png', 'montage-fake-0001.png']
     with open(files[0]) as f:
-        header, row = f.read().strip().split('\\n')
+        header, row = f.read().strip().split('\n')
     assert header == 'epoch,d_loss,g_loss' and row.startswith('1,')
     for path, t in ((files[1], real), (files[2], fake)):
         img = png.decode(open(path, 'rb').read())
