@@ -1884,6 +1884,7 @@ struct FusedBwdArgs {
   int nhm, nwm, dh_min, dw_min, ntap;
   int KP, PP, wpitch;    // K per tap padded to 32; LDS pixel pitch; filter column pitch (elements)
   int TA, ntr;           // anchor rows per workgroup, row tiles per image
+  int TW, ntc;           // anchor columns per workgroup, column tiles per row tile (wide images: the halo tile would not fit)
   int y_off;             // LDS byte offset of the halo tile
   FastDiv fd_vpp, fd_hc;
   int act, mask_mode, accumulate;
@@ -1896,9 +1897,10 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
   bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
   bf16_t* sY = reinterpret_cast<bf16_t*>(smem + a.y_off);     // past the zero-filled tail of the filter's last wave instruction
   const int tid = threadIdx.x;
-  const int img = blockIdx.x / a.ntr, rt = blockIdx.x - img * a.ntr;
-  const int a0 = rt * a.TA;
-  const int HR = a.TA + a.nhm - 1, HC = a.GW + a.nwm - 1;     // halo tile (pixels)
+  const int tile = blockIdx.x / a.ntc, ct = blockIdx.x - tile * a.ntc;
+  const int img = tile / a.ntr, rt = tile - img * a.ntr;
+  const int a0 = rt * a.TA, c0 = ct * a.TW;
+  const int HR = a.TA + a.nhm - 1, HC = a.TW + a.nwm - 1;     // halo tile (pixels)
 
   // ---- stage the merged filter (straight copy) and the halo tile by LDS-DMA: every 16-byte chunk of both images
   // is one lane of a wave instruction (destination lane-linear), halo pixels outside the image, the pitch padding
@@ -1921,7 +1923,7 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
       const int g = g0 + lane;
       const int pix = (int)fd_div((unsigned)g, a.fd_vpp), v = g - pix * vpp;
       const int hr = (int)fd_div((unsigned)pix, a.fd_hc), hc = pix - hr * HC;
-      const int r = a0 + hr + a.dh_min, c = hc + a.dw_min;
+      const int r = a0 + hr + a.dh_min, c = c0 + hc + a.dw_min;
       const bool ok = pix < npx && v < vreal && (unsigned)r < (unsigned)a.SH && (unsigned)c < (unsigned)a.SW;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, (lds_ptr_t)(sYb + g0 * 16), 16, ok ? (unsigned)(((r * a.SW + c) * a.Cs + v * 8) * 2) : OOB_OFFSET, 0, 0, 0);
     }
@@ -1929,7 +1931,7 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
   __syncthreads();
 
   const int r16 = lane & 15, q = lane >> 4;
-  const int npix = a.TA * a.GW, ntile = (npix + 15) / 16;
+  const int npix = a.TA * a.TW, ntile = (npix + 15) / 16;
   const int kcn = a.KP / 32;
   const bf16_t* wrow = sW + r16 * a.wpitch + q * 8;
   for (int t0 = wave; t0 < ntile; t0 += 2 * NWAVE) {
@@ -1940,8 +1942,8 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
     const bool ok0 = p0 < npix, ok1 = has1 && p1 < npix;
     p0 = ok0 ? p0 : 0;
     p1 = ok1 ? p1 : 0;
-    const int al0 = p0 / a.GW, b0 = p0 - al0 * a.GW;
-    const int al1 = p1 / a.GW, b1 = p1 - al1 * a.GW;
+    const int al0 = p0 / a.TW, b0 = p0 - al0 * a.TW;
+    const int al1 = p1 / a.TW, b1 = p1 - al1 * a.TW;
     const bf16_t* base0 = sY + (size_t)(al0 * HC + b0) * a.PP + q * 8;
     const bf16_t* base1 = sY + (size_t)(al1 * HC + b1) * a.PP + q * 8;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -1964,8 +1966,8 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
       const bool ok = h ? ok1 : ok0;
       if (!ok) continue;
       const f32x4 acc = h ? acc1 : acc0;
-      const int ar = a0 + (h ? al1 : al0), bc = h ? b1 : b0;
-      if (ar >= a.GH) continue;
+      const int ar = a0 + (h ? al1 : al0), bc = c0 + (h ? b1 : b0);
+      if (ar >= a.GH || bc >= a.GW) continue;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int col = q * 4 + e;
@@ -2553,7 +2555,7 @@ int plan_bwd_classes(const TdgConvDesc* d, BwdClassPlan* cls) {
 
 // ---- fused-class backward-data (bwd_fused_kernel): when it applies and its geometry ---------------------------
 struct FusedPlan {
-  int nhm, nwm, dh_min, dw_min, ntap, ke, KP, PP, wpitch, TA, ntr, GH, GW, y_off;
+  int nhm, nwm, dh_min, dw_min, ntap, ke, KP, PP, wpitch, TA, ntr, TW, ntc, GH, GW, y_off;
   size_t w_bytes, lds;
 };
 
@@ -2586,16 +2588,31 @@ bool plan_bwd_fused(const TdgConvDesc* d, FusedPlan* f) {
   f->GW = (d->w + 1) / 2;
   f->w_bytes = (size_t)16 * f->wpitch * 2;
   const size_t budget = 150 * 1024;
-  const size_t row_bytes = (size_t)(f->GW + f->nwm - 1) * f->PP * 2;
   f->y_off = (int)tdg_round_up((long long)f->w_bytes, 1024);
   const size_t fixed = (size_t)f->y_off + (size_t)f->KP * 2 + 1024;   // + slack + the tail of the halo's last wave instruction
-  if (fixed + (size_t)f->nhm * row_bytes > budget) return false;
-  int ta = (int)((budget - fixed) / row_bytes) - (f->nhm - 1);
-  if (ta > f->GH) ta = f->GH;
-  if (ta < 1) return false;
-  f->ntr = tdg_ceil_div(f->GH, ta);
-  f->TA = tdg_ceil_div(f->GH, f->ntr);                        // balanced row tiles
-  f->lds = fixed + (size_t)(f->TA + f->nhm - 1) * row_bytes;
+  // Column tiles: the halo tile holds (TA + nhm - 1) x (TW + nwm - 1) small-side pixels.  With full-width rows a wide,
+  // many-channel small side (pix2pix d8: 128 anchors x 128 channels) fits ONE anchor row, i.e. every source row is staged
+  // nhm = 3 times; the fewest column tiles whose halo re-read factor (rows and columns) is within 10 % of the best wins.
+  int best_ntc = 0, best_ta = 0;
+  double best_amp = 1e30;
+  for (int ntc = 1; ntc <= 8; ++ntc) {
+    const int tw = tdg_ceil_div(f->GW, ntc);
+    const size_t row_bytes = (size_t)(tw + f->nwm - 1) * f->PP * 2;
+    if (fixed + (size_t)f->nhm * row_bytes > budget) continue;
+    int ta = (int)((budget - fixed) / row_bytes) - (f->nhm - 1);
+    if (ta > f->GH) ta = f->GH;
+    if (ta < 1) continue;
+    const int ntr = tdg_ceil_div(f->GH, ta);
+    ta = tdg_ceil_div(f->GH, ntr);                            // balanced row tiles
+    const double amp = (double)(ta + f->nhm - 1) / ta * (double)(tw + f->nwm - 1) / tw;
+    if (amp < best_amp * 0.9) { best_amp = amp; best_ntc = ntc; best_ta = ta; }
+  }
+  if (!best_ntc) return false;
+  f->ntc = best_ntc;
+  f->TW = tdg_ceil_div(f->GW, best_ntc);
+  f->TA = best_ta;
+  f->ntr = tdg_ceil_div(f->GH, best_ta);
+  f->lds = fixed + (size_t)(f->TA + f->nhm - 1) * (size_t)(f->TW + f->nwm - 1) * f->PP * 2;
   return true;
 }
 
@@ -2961,9 +2978,9 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     f.OH = d->h; f.OW = d->w; f.Cso = d->cs; f.C = d->c;
     f.GH = fp.GH; f.GW = fp.GW;
     f.nhm = fp.nhm; f.nwm = fp.nwm; f.dh_min = fp.dh_min; f.dw_min = fp.dw_min; f.ntap = fp.ntap;
-    f.KP = fp.KP; f.PP = fp.PP; f.wpitch = fp.wpitch; f.TA = fp.TA; f.ntr = fp.ntr; f.y_off = fp.y_off;
+    f.KP = fp.KP; f.PP = fp.PP; f.wpitch = fp.wpitch; f.TA = fp.TA; f.ntr = fp.ntr; f.TW = fp.TW; f.ntc = fp.ntc; f.y_off = fp.y_off;
     f.fd_vpp = make_fastdiv(fp.PP / 8);
-    f.fd_hc = make_fastdiv(fp.GW + fp.nwm - 1);
+    f.fd_hc = make_fastdiv(fp.TW + fp.nwm - 1);
     static bool attr_set = false;
     if (!attr_set) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2971,7 +2988,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     }
     tdg_note_kernel("bwd_fused_kernel<bf16>");
     tdg_timing_start("bwd_fused_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
-    hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr), dim3(512), fp.lds, (hipStream_t)stream, f);
+    hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr * fp.ntc), dim3(512), fp.lds, (hipStream_t)stream, f);
     tdg_timing_stop((hipStream_t)stream);
     TDG_HIP_LAUNCH_CHECK("bwd_fused");
     return TDG_OK;

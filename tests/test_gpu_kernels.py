@@ -45,6 +45,7 @@ CONV_CASES = [
     (2, 64, 64, 1, 128, 4, 2),     # pix2pix d8 (deconv 128 -> 1): one-channel big side, 128-column LDS-DMA tile
     (3, 32, 32, 64, 128, 4, 2),    # pix2pix e2 / m2: 128-column LDS-DMA tile, 64-channel input
     (2, 16, 16, 128, 256, 4, 2),   # 256 columns = two 128-column tiles
+    (1, 256, 256, 1, 128, 4, 2),   # pix2pix d8 at full width: fused-class backward-data with COLUMN tiles (128 anchors x 128 channels)
     (80, 16, 16, 8, 400, 5, 2),    # 400 columns on an under-filled grid: 128 x 112 tiles (four column tiles, the last one 64 wide);
                                    # the smaller 400-column cases above take the 64 x 112 tile
 ]
