@@ -65,6 +65,9 @@ SIGNATURES = {
     'tdg_rowdot': (_i, [_i, _vp, _i, _i, _vp, _vp, _i, _vp, _vp]),
     'tdg_rowouter': (_i, [_i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
     'tdg_col_finalize_sum': (_i, [_vp, _i, _i, _vp, _f, _vp]),
+    'tdg_instance_norm_fwd': (_i, [_i, _vp, _i, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp]),
+    'tdg_instance_norm_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    'tdg_add_act': (_i, [_i, _vp, _vp, _sz, _i, _f, _vp, _vp]),
     'tdg_bn_fwd_from_partials': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp]),
     'tdg_colsum_weighted': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _f, _vp, _sz, _vp]),
     'tdg_colsum_workspace_bytes': (_sz, [_i, _i]),

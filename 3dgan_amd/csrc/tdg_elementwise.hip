@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
 }
 
 // finalize modes
-enum { FIN_BN_STATS = 0, FIN_BN_BWD = 1, FIN_ACC = 2 };
+enum { FIN_BN_STATS = 0, FIN_BN_BWD = 1, FIN_ACC = 2, FIN_ACC2 = 3 };   // ACC2: both planes, out0 / out1
 struct FinArgs {
   const float* partial; int nblk, C, rows;
   const void* x0;       // first row of the tensor (pivot) for BN stats
@@ -349,6 +349,9 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
     a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
     a.out1[c] = s0 * inv;
     a.out1[a.C + c] = s1 * inv;
+  } else if (MODE == FIN_ACC2) {
+    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
+    a.out1[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out1[c] : 0.f) + s1;
   } else {
     a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
   }
@@ -564,6 +567,117 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
     hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
   })
   TDG_HIP_LAUNCH_CHECK("colsum_weighted");
+  return TDG_OK;
+}
+
+// ============================================================================ instance norm (hem/ops/images.py:73-89)
+// y = scale[c] * (x - mu[n,c]) / sqrt(var[n,c] + eps) + shift[c], moments over the H*W positions of ONE image (biased),
+// followed by the layer's activation.  One workgroup per (image, 64-channel chunk): 64 channel lanes x 4 row lanes.
+// stats[(n*2 + 0)*c + ch] = mu, [(n*2 + 1)*c + ch] = rstd (kept for the backward).
+template <typename T>
+__global__ void __launch_bounds__(256) instance_norm_fwd_kernel(const T* __restrict__ u, int hw, int c, int cs,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, float eps,
+                                                               int act, float leak, T* __restrict__ h, int hcs, float* __restrict__ stats) {
+  __shared__ float sh[2][4][64];
+  const int n = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
+  const bool okc = ch < c;
+  const T* un = u + (size_t)n * hw * cs;
+  const float pivot = okc ? to_f32<T>(un[ch]) : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  if (okc)
+    for (int r = ty; r < hw; r += 4) { const float d = to_f32<T>(un[(size_t)r * cs + ch]) - pivot; s0 += d; s1 += d * d; }
+  sh[0][ty][tx] = s0; sh[1][ty][tx] = s1;
+  __syncthreads();
+  s0 = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
+  s1 = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
+  if (!okc) return;
+  const float md = s0 / (float)hw, var = fmaxf(s1 / (float)hw - md * md, 0.f);
+  const float mu = pivot + md, rstd = rsqrtf(var + eps);
+  if (ty == 0) { stats[((size_t)n * 2 + 0) * c + ch] = mu; stats[((size_t)n * 2 + 1) * c + ch] = rstd; }
+  const float g = scale[ch], b = shift[ch];
+  T* hn = h + (size_t)n * hw * hcs;
+  for (int r = ty; r < hw; r += 4)
+    hn[(size_t)r * hcs + ch] = from_f32<T>(apply_act(g * (to_f32<T>(un[(size_t)r * cs + ch]) - mu) * rstd + b, act, leak));
+}
+extern "C" int tdg_instance_norm_fwd(int dtype, const void* u, int n, int hw, int c, int cs, const float* scale, const float* shift,
+                                     float eps, int act, float leak, void* h, int h_cs, float* stats, void* stream) {
+  TDG_CHECK_ARG(u && scale && shift && h && stats && n > 0 && hw > 0 && c > 0 && cs >= c && h_cs >= c, "tdg_instance_norm_fwd: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(instance_norm_fwd_kernel<T>, dim3(n, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(u),
+                       hw, c, cs, scale, shift, eps, act, leak, static_cast<T*>(h), h_cs, stats);
+  })
+  TDG_HIP_LAUNCH_CHECK("instance_norm_fwd");
+  return TDG_OK;
+}
+// backward: g = dh * act'(pre), pre = scale * xhat + shift;  du = scale * rstd * (g - mean(g) - xhat * mean(g * xhat));
+// per-image partials part[(n*2 + 0)*c + ch] = sum g * xhat (dscale), [(n*2 + 1)*c + ch] = sum g (dshift)
+template <typename T>
+__global__ void __launch_bounds__(256) instance_norm_bwd_kernel(const T* __restrict__ dh, int dhcs, const T* __restrict__ u, int hw, int c,
+                                                               int cs, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ stats, int act, float leak, T* __restrict__ du,
+                                                               float* __restrict__ part) {
+  __shared__ float sh[2][4][64];
+  const int n = blockIdx.x, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int ch = blockIdx.y * 64 + tx;
+  const bool okc = ch < c;
+  const T* un = u + (size_t)n * hw * cs;
+  const T* dn = dh + (size_t)n * hw * dhcs;
+  const float mu = okc ? stats[((size_t)n * 2 + 0) * c + ch] : 0.f, rstd = okc ? stats[((size_t)n * 2 + 1) * c + ch] : 0.f;
+  const float g0 = okc ? scale[ch] : 0.f, b0 = okc ? shift[ch] : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  if (okc)
+    for (int r = ty; r < hw; r += 4) {
+      const float xh = (to_f32<T>(un[(size_t)r * cs + ch]) - mu) * rstd;
+      const float g = to_f32<T>(dn[(size_t)r * dhcs + ch]) * act_deriv_from_pre(g0 * xh + b0, act, leak);
+      s0 += g; s1 += g * xh;
+    }
+  sh[0][ty][tx] = s0; sh[1][ty][tx] = s1;
+  __syncthreads();
+  s0 = sh[0][0][tx] + sh[0][1][tx] + sh[0][2][tx] + sh[0][3][tx];
+  s1 = sh[1][0][tx] + sh[1][1][tx] + sh[1][2][tx] + sh[1][3][tx];
+  if (!okc) return;
+  if (ty == 0) { part[((size_t)n * 2 + 0) * c + ch] = s1; part[((size_t)n * 2 + 1) * c + ch] = s0; }
+  const float m0 = s0 / (float)hw, m1 = s1 / (float)hw;
+  T* dun = du + (size_t)n * hw * cs;
+  for (int r = ty; r < hw; r += 4) {
+    const float xh = (to_f32<T>(un[(size_t)r * cs + ch]) - mu) * rstd;
+    const float g = to_f32<T>(dn[(size_t)r * dhcs + ch]) * act_deriv_from_pre(g0 * xh + b0, act, leak);
+    dun[(size_t)r * cs + ch] = from_f32<T>(g0 * rstd * (g - m0 - xh * m1));
+  }
+}
+extern "C" int tdg_instance_norm_bwd(int dtype, const void* dh, int dh_cs, const void* u, int n, int hw, int c, int cs,
+                                     const float* scale, const float* shift, const float* stats, int act, float leak, void* du,
+                                     float* dscale, float* dshift, float beta, void* workspace, size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(dh && u && scale && shift && stats && du && dscale && dshift && workspace && n > 0 && hw > 0 && c > 0 && cs >= c && dh_cs >= c,
+                "tdg_instance_norm_bwd: bad argument");
+  if (workspace_bytes < (size_t)n * 2 * c * sizeof(float)) { tdg_set_error("tdg_instance_norm_bwd: workspace too small"); return TDG_EWORKSPACE; }
+  float* part = static_cast<float*>(workspace);
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = part; f.nblk = n; f.C = c; f.rows = 1; f.out0 = dscale; f.out1 = dshift; f.beta_acc = beta;
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(instance_norm_bwd_kernel<T>, dim3(n, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(dh),
+                       dh_cs, static_cast<const T*>(u), hw, c, cs, scale, shift, stats, act, leak, static_cast<T*>(du), part);
+    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC2>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, f);
+  })
+  TDG_HIP_LAUNCH_CHECK("instance_norm_bwd");
+  return TDG_OK;
+}
+
+// out = act(a + b) on flat buffers of one layout (the residual sum of hem/ops/layers.py:215-320; act NONE: plain add)
+template <typename T>
+__global__ void __launch_bounds__(256) add_act_kernel(const T* __restrict__ a, const T* __restrict__ b, size_t n, int act, float leak,
+                                                     T* __restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    out[i] = from_f32<T>(apply_act(to_f32<T>(a[i]) + to_f32<T>(b[i]), act, leak));
+}
+extern "C" int tdg_add_act(int dtype, const void* a, const void* b, size_t n, int act, float leak, void* out, void* stream) {
+  TDG_CHECK_ARG(a && b && out && n > 0, "tdg_add_act: bad argument");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(add_act_kernel<T>, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(a),
+                       static_cast<const T*>(b), n, act, leak, static_cast<T*>(out));
+  })
+  TDG_HIP_LAUNCH_CHECK("add_act");
   return TDG_OK;
 }
 

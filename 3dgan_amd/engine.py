@@ -317,20 +317,31 @@ class SeqNet:
                 L.h = out_act if (last and out_act is not None) else K.Act(capacity * rpi, oh, ow, oc, dtype, device)
                 if (L.h.n, L.h.h, L.h.w, L.h.c) != (capacity * rpi, oh, ow, oc):
                     raise ValueError('out_act does not match the last layer output')
-                L.pre = L.h.like() if spec.use_bn else None
+                L.pre = L.h.like() if spec.normed and spec.kind != 'residual' else None       # batch norm: the normalised pre-activation; instance norm: the conv output
                 L.delta = L.h.like()
-                sep = spec.use_bn or L.act.code in (K.ACT_TANH, K.ACT_SIGMOID)
+                sep = spec.normed or spec.kind == 'residual' or L.act.code in (K.ACT_TANH, K.ACT_SIGMOID)
                 L.gout = L.h.like() if sep else L.delta
                 if last and out_grad is not None:
                     if not sep:
                         L.delta = out_grad
                     L.gout = out_grad
-                if spec.use_bn:
+                if spec.use_bn and spec.kind != 'residual':
                     L.bn_stats = [torch.zeros(2 * oc, dtype=torch.float32, device=device) for _ in range(n_bn_passes)]
                     L.bn_names = [net.bn_name(p, idx) for p in range(n_bn_passes)]
+                if spec.use_in:
+                    L.in_stats = torch.zeros(capacity * rpi * 2 * oc, dtype=torch.float32, device=device)
+                    L.in_names = (net.var_name(spec, 'scale'), net.var_name(spec, 'shift'))
+                if (spec.use_in or spec.kind == 'residual') and tangent_capacity:
+                    raise NotImplementedError('layer %s: no gradient-penalty tangent pass through instance norm / residual blocks' % spec.name)
+                if spec.kind == 'residual':
+                    L.res = Residual(self, L, net, idx, capacity * rpi, n_bn_passes)
+                    L.conv = L.tan = L.pre = None
+                    self.layers.append(L)
+                    prev, prev_g = L.h, L.gout
+                    continue
                 if spec.kind == 'deconv2d':
                     big, small = L.h, L.inp
-                else:
+                else:                                  # conv2d, dense, and conv A of a residual block
                     big, small = L.inp, L.h
                 if spec.padding == 'SAME':
                     pt = max((small.h - 1) * spec.stride + spec.k - big.h, 0) // 2
@@ -348,18 +359,29 @@ class SeqNet:
     # -- variables ---------------------------------------------------------------------------------
     def declare_variables(self):
         for L in self.layers:
+            if L.spec.kind == 'residual':
+                L.res.declare(self.store)
+                continue
             self.store.declare(L.wname, L.spec.filter_shape)
             self.store.declare(L.bname, (L.spec.out_size,))
+            if L.spec.use_in:
+                for name in L.in_names:
+                    self.store.declare(name, (L.spec.out_size,))
         for p in range(self.n_bn_passes):
             for L in self.layers:
-                if L.spec.use_bn:
+                if L.spec.kind == 'residual':
+                    L.res.declare_bn(self.store, p)
+                elif L.spec.use_bn:
                     self.store.declare(L.bn_names[p], (L.spec.out_size,))
 
     def init_variables(self, gen):
         """Fresh variables: xavier-uniform weights and biases, zero betas (App. A-3/A-4);
         'normal0.02' (pix2pix, hem/models/pix2pix.py:180) draws N(0, 0.02)."""
         for L in self.layers:
-            for name, shape in ((L.wname, L.spec.filter_shape), (L.bname, (L.spec.out_size,))):
+            if L.spec.use_in:
+                self.store[L.in_names[0]].fill_(1.0)        # scale: ones_initializer; shift stays at zeros (hem/ops/images.py:79-80)
+            pairs = L.res.variables() if L.spec.kind == 'residual' else ((L.wname, L.spec.filter_shape), (L.bname, (L.spec.out_size,)))
+            for name, shape in pairs:
                 cpu = torch.empty(shape, dtype=torch.float32)
                 if L.spec.init == 'xavier':
                     xavier_uniform_(cpu, shape, gen)
@@ -371,7 +393,12 @@ class SeqNet:
         """Refresh the packed GEMM operands from the f32 masters (after every optimizer step)."""
         if self._pack_jobs is None:
             # masters and packed buffers never move, so the job table is built once
-            jl = [L.conv.pack_job(self.store[L.wname]) for L in self.layers if not L.rowdot]
+            jl = []
+            for L in self.layers:
+                if L.spec.kind == 'residual':
+                    jl += L.res.pack_jobs(self.store)
+                elif not L.rowdot:
+                    jl.append(L.conv.pack_job(self.store[L.wname]))
             self._pack_jobs = K.make_pack_jobs(jl) if jl else ()
         if len(self._pack_jobs):
             K.pack_all(self._pack_jobs)
@@ -386,8 +413,14 @@ class SeqNet:
                 _lib.call('tdg_rowdot', self.dtype, L.inp.ptr(r0), rn, cols, K.ptr(self.store[L.wname]),
                           K.ptr(self.store[L.bname]), L.act.code, K.ptr(L.out, 4 * r0), K.stream())
                 continue
+            if L.spec.kind == 'residual':
+                L.res.forward(r0, rn, bn_pass)
+                continue
             bias = self.store[L.bname]
-            if L.spec.use_bn:
+            if L.spec.use_in:
+                epi = K.epilogue(bias=bias)
+                target = L.pre
+            elif L.spec.use_bn:
                 # the GEMM's epilogue also emits the batch statistics' column partials of the tile it stores
                 epi = K.colsum_epilogue(self.ws, rn * L.h.h * L.h.w, L.spec.out_size, K.COL_BN, bias=bias)
                 target = L.pre
@@ -398,7 +431,10 @@ class SeqNet:
                 L.conv.bwd_data(L.inp.ptr(r0), target.ptr(r0), rn, epi)
             else:
                 L.conv.fwd(L.inp.ptr(r0), target.ptr(r0), rn, epi)
-            if L.spec.use_bn:
+            if L.spec.use_in:
+                K.in_fwd(L.pre, rn, L.spec.out_size, self.store[L.in_names[0]], self.store[L.in_names[1]], L.act.code, L.h,
+                         L.in_stats[r0 * 2 * L.spec.out_size:], leak=L.act.leak, u_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
+            elif L.spec.use_bn:
                 rows = rn * L.h.h * L.h.w
                 if K.nblk(epi):
                     K.bn_fwd_from_partials(epi, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
@@ -430,7 +466,7 @@ class SeqNet:
             d0, dn, dimg = r0, rn, img0
             if below is None and want_dx and dx_images is not None:      # restrict the input gradient
                 d0, dn, dimg = dx_images[0] * L.rpi, dx_images[1] * L.rpi, dx_images[0]
-            if below is not None and not below.spec.use_bn and below.act.code in (K.ACT_LRELU, K.ACT_RELU):
+            if below is not None and not below.spec.normed and below.spec.kind != 'residual' and below.act.code in (K.ACT_LRELU, K.ACT_RELU):
                 mmode = K.MASK_LRELU if below.act.code == K.ACT_LRELU else K.MASK_RELU
                 msrc, mleak = below.h, below.act.leak
             else:
@@ -445,9 +481,25 @@ class SeqNet:
                     _lib.call('tdg_rowouter', self.dtype, K.ptr(L.seed, 4 * d0), K.ptr(self.store[L.wname]), dn, cols,
                               mmode, mleak, msrc.ptr(dimg * below.rpi) if msrc is not None else None, L.gin.ptr(d0), K.stream())
                 continue
+            if L.spec.kind == 'residual':
+                L.res.backward(r0, rn, q0, qn, bn_pass, want_params, beta, need_in, mmode, mleak,
+                               msrc.ptr(dimg * below.rpi) if msrc is not None else None)
+                have_db = None
+                continue
             # dL/d(conv output)
             hw = L.h.h * L.h.w
-            if L.spec.use_bn:
+            if L.spec.use_in:
+                scale, shift = self.store[L.in_names[0]], self.store[L.in_names[1]]
+                if want_params:
+                    dsc, dsh = g(L.in_names[0]), g(L.in_names[1])
+                else:
+                    if getattr(L, 'in_sink', None) is None:
+                        L.in_sink = torch.zeros(2 * L.spec.out_size, dtype=torch.float32, device=self.device)
+                    dsc, dsh = L.in_sink[:L.spec.out_size], L.in_sink[L.spec.out_size:]
+                K.in_bwd(self.ws, L.gout, L.pre, rn, L.spec.out_size, scale, shift, L.in_stats[r0 * 2 * L.spec.out_size:], L.act.code,
+                         L.delta, dsc, dsh, leak=L.act.leak, beta=beta if want_params else 0.0,
+                         dh_ptr=L.gout.ptr(r0), u_ptr=L.pre.ptr(r0), du_ptr=L.delta.ptr(r0))
+            elif L.spec.use_bn:
                 if want_params:
                     dbeta = g(L.bn_names[bn_pass])
                 else:                                   # keep the stored beta gradient of an earlier pass intact
@@ -478,7 +530,7 @@ class SeqNet:
                 mptr = msrc.ptr(dimg * below.rpi) if msrc is not None else None
                 # what this GEMM stores IS delta of the layer below when that layer has no batch norm and a (l)relu / identity
                 # activation: its bias gradient = the column sums of the stored tiles, restricted to the parameter images
-                fuse = (want_params and below is not None and not below.rowdot and not below.spec.use_bn and
+                fuse = (want_params and below is not None and not below.rowdot and not below.spec.normed and below.spec.kind != 'residual' and
                         below.act.code in (K.ACT_LRELU, K.ACT_RELU, K.ACT_NONE) and below.gout is below.delta and
                         L.rpi == 1 and below.rpi == 1 and p0 == img0 and 0 < pn <= n and (d0, dn) == (r0, rn))
                 if fuse:
@@ -507,7 +559,7 @@ class SeqNet:
                 cols = L.spec.in_size
                 K.colsum_weighted(self.ws, self.dtype, t_prev.ptr(0), rn, cols, cols, None, g(L.wname), beta)
                 break
-            if L.spec.use_bn or L.spec.kind == 'deconv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
+            if L.spec.normed or L.spec.kind != 'conv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
                 raise NotImplementedError('tangent pass: layer %s is not a BN-free (l)relu conv' % L.spec.name)
             L.tan_src = _alias_rows(t_prev, L.rpi, *L.spec.in_shape) if t_prev is not self.tan_in else self.tan_in
             mmode = K.MASK_LRELU if L.act.code == K.ACT_LRELU else K.MASK_RELU
@@ -547,13 +599,112 @@ class SeqNet:
                 cols = L.spec.in_size
                 K.colsum_weighted(self.ws, self.dtype, t_prev.ptr(0), rn, cols, cols, None, g(L.wname), beta)
                 break
-            if L.spec.use_bn or L.spec.kind == 'deconv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
+            if L.spec.normed or L.spec.kind != 'conv2d' or L.act.code not in (K.ACT_LRELU, K.ACT_RELU):
                 raise NotImplementedError('tangent pass: layer %s is not a BN-free (l)relu conv' % L.spec.name)
             t_in = _alias_rows(t_prev, L.rpi, *L.spec.in_shape) if t_prev is not self.tan_in else self.tan_in
             L.conv.bwd_filter(t_in.ptr(0), L.delta.ptr(r0), g(L.wname), rn, beta)
             mmode = K.MASK_LRELU if L.act.code == K.ACT_LRELU else K.MASK_RELU
             L.conv.fwd(t_in.ptr(0), L.tan.ptr(0), rn, K.epilogue(mask_mode=mmode, leak=L.act.leak, mask_src=L.h.ptr(r0)))
             t_prev = L.tan
+
+
+class Residual:
+    """The two-conv residual block of the gen-2 layer surface (hem/ops/layers.py:215-320) as one SeqNet layer:
+        S = conv_A(x) + b_A (`shortcut`);  hA = act([bn](S));  T = conv_B(hA) + b_B;  out = act([bn](T) + S).
+    The block's output and incoming gradient are separate tensors (L.h / L.gout: the consumer does not apply this layer's
+    activation derivative); its own backward delivers dL/dx with the derivative mask of the layer below, like any conv."""
+
+    def __init__(self, seq, L, net, idx, capacity, n_bn_passes):
+        self.seq, self.L, self.net, self.idx = seq, L, net, idx
+        spec = self.spec = L.spec
+        dt, dev = seq.dtype, seq.device
+        oh, ow, oc = spec.out_shape
+        A = lambda: K.Act(capacity, oh, ow, oc, dt, dev)
+        self.S, self.hA, self.T = A(), A(), A()                       # shortcut, first activation, conv B output
+        self.dZ, self.dT, self.dhA, self.dS = A(), A(), A(), A()
+        self.preA = A() if spec.use_bn else None                      # batch-normalised S / T (the activations' inputs)
+        self.preB = A() if spec.use_bn else None
+        pt = max((oh - 1) + spec.k - spec.in_shape[0], 0) // 2
+        pl = max((ow - 1) + spec.k - spec.in_shape[1], 0) // 2
+        self.convA = K.Conv(L.inp, self.S, spec.k, spec.k, 1, pt, pl)
+        self.convB = K.Conv(self.hA, self.T, spec.k, spec.k, 1, pt, pl)
+        self.names = {w: '%s/vars/%s%s/%s' % (net.name, spec.name, ab, w2) for ab in 'AB' for w2 in ('weights', 'bias')
+                      for w in ['%s%s' % (ab, w2[0])]}              # Aw, Ab, Bw, Bb
+        self.shapes = {'Aw': (spec.k, spec.k, spec.in_size, oc), 'Ab': (oc,), 'Bw': (spec.k, spec.k, oc, oc), 'Bb': (oc,)}
+        if spec.use_bn:
+            self.statsA = [torch.zeros(2 * oc, dtype=torch.float32, device=dev) for _ in range(n_bn_passes)]
+            self.statsB = [torch.zeros(2 * oc, dtype=torch.float32, device=dev) for _ in range(n_bn_passes)]
+            self.bnA = [net.bn_name(p, idx, 0) for p in range(n_bn_passes)]
+            self.bnB = [net.bn_name(p, idx, 1) for p in range(n_bn_passes)]
+
+    def declare(self, store):
+        for k in ('Aw', 'Ab', 'Bw', 'Bb'):
+            store.declare(self.names[k], self.shapes[k])
+
+    def declare_bn(self, store, p):
+        if self.spec.use_bn:
+            store.declare(self.bnA[p], (self.spec.out_size,))
+            store.declare(self.bnB[p], (self.spec.out_size,))
+
+    def variables(self):
+        return [(self.names[k], self.shapes[k]) for k in ('Aw', 'Ab', 'Bw', 'Bb')]
+
+    def pack_jobs(self, store):
+        return [self.convA.pack_job(store[self.names['Aw']]), self.convB.pack_job(store[self.names['Bw']])]
+
+    def forward(self, r0, rn, bn_pass):
+        st, sp, L, ws = self.seq.store, self.spec, self.L, self.seq.ws
+        act, oc, dt = L.act, sp.out_size, self.seq.dtype
+        rows = rn * self.S.h * self.S.w
+        nel = rn * self.S.image_elems
+        self.convA.fwd(L.inp.ptr(r0), self.S.ptr(r0), rn, K.epilogue(bias=st[self.names['Ab']]))
+        if sp.use_bn:
+            K.bn_fwd(ws, self.S, oc, st[self.bnA[bn_pass]], act.code, self.preA, self.hA, self.statsA[bn_pass], rows=rows,
+                     leak=act.leak, u_ptr=self.S.ptr(r0), pre_ptr=self.preA.ptr(r0), h_ptr=self.hA.ptr(r0))
+        else:
+            _lib.call('tdg_bias_act', dt, self.S.ptr(r0), rows, oc, self.S.cs, None, act.code, act.leak, self.hA.ptr(r0), K.stream())
+        self.convB.fwd(self.hA.ptr(r0), self.T.ptr(r0), rn, K.epilogue(bias=st[self.names['Bb']]))
+        branch = self.T
+        if sp.use_bn:
+            K.bn_fwd(ws, self.T, oc, st[self.bnB[bn_pass]], K.ACT_NONE, self.preB, self.preB, self.statsB[bn_pass], rows=rows,
+                     u_ptr=self.T.ptr(r0), pre_ptr=self.preB.ptr(r0), h_ptr=self.preB.ptr(r0))
+            branch = self.preB
+        K.add_act(dt, branch.ptr(r0), self.S.ptr(r0), nel, L.h.ptr(r0), act.code, act.leak)          # act(branch + shortcut)
+
+    def backward(self, r0, rn, q0, qn, bn_pass, want_params, beta, need_in, mmode, mleak, mptr):
+        st, g, sp, L, ws = self.seq.store, self.seq.store.grad, self.spec, self.L, self.seq.ws
+        act, oc, dt = L.act, sp.out_size, self.seq.dtype
+        hw = self.S.h * self.S.w
+        rows, nel = rn * hw, rn * self.S.image_elems
+        sink = self.__dict__.setdefault('_sink', torch.zeros(oc, dtype=torch.float32, device=self.seq.device))
+        # dZ = dOut * act'(out)
+        _lib.call('tdg_act_bwd', dt, L.gout.ptr(r0), L.h.ptr(r0), nel, act.code, act.leak, self.dZ.ptr(r0), K.stream())
+        if sp.use_bn:
+            K.bn_bwd(ws, self.dZ, self.preB, oc, st[self.bnB[bn_pass]], self.statsB[bn_pass], K.ACT_NONE, self.dT,
+                     g(self.bnB[bn_pass]) if want_params else sink, rows=rows, beta_acc=0.0,
+                     dh_ptr=self.dZ.ptr(r0), pre_ptr=self.preB.ptr(r0), du_ptr=self.dT.ptr(r0))
+            dT = self.dT
+        else:
+            dT = self.dZ
+        if want_params and qn > 0:
+            K.bias_grad(ws, dT, oc, g(self.names['Bb']), rows=qn * hw, beta=beta, dy_ptr=dT.ptr(q0))
+            self.convB.bwd_filter(self.hA.ptr(q0), dT.ptr(q0), g(self.names['Bw']), qn, beta)
+        if sp.use_bn:
+            self.convB.bwd_data(dT.ptr(r0), self.dhA.ptr(r0), rn)
+            K.bn_bwd(ws, self.dhA, self.preA, oc, st[self.bnA[bn_pass]], self.statsA[bn_pass], act.code, self.dS,
+                     g(self.bnA[bn_pass]) if want_params else sink, rows=rows, leak=act.leak, beta_acc=0.0,
+                     dh_ptr=self.dhA.ptr(r0), pre_ptr=self.preA.ptr(r0), du_ptr=self.dS.ptr(r0))
+        else:
+            m = K.MASK_LRELU if act.code == K.ACT_LRELU else (K.MASK_RELU if act.code == K.ACT_RELU else K.MASK_NONE)
+            if m == K.MASK_NONE and act.code != K.ACT_NONE:
+                raise NotImplementedError('residual %s: activation %s without batch norm' % (sp.name, act.name))
+            self.convB.bwd_data(dT.ptr(r0), self.dS.ptr(r0), rn, K.epilogue(mask_mode=m, leak=act.leak, mask_src=self.hA.ptr(r0)))
+        K.add_act(dt, self.dS.ptr(r0), self.dZ.ptr(r0), nel, self.dS.ptr(r0))                # + the shortcut's gradient
+        if want_params and qn > 0:
+            K.bias_grad(ws, self.dS, oc, g(self.names['Ab']), rows=qn * hw, beta=beta, dy_ptr=self.dS.ptr(q0))
+            self.convA.bwd_filter(L.inp.ptr(q0), self.dS.ptr(q0), g(self.names['Aw']), qn, beta)
+        if need_in:
+            self.convA.bwd_data(self.dS.ptr(r0), L.gin.ptr(r0), rn, K.epilogue(mask_mode=mmode, leak=mleak, mask_src=mptr))
 
 
 def _alias_rows(act, rpi, h, w, c):

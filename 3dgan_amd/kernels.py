@@ -326,3 +326,20 @@ def colsum_weighted(ws, dtype, x_ptr, rows, cols, cs, coef, dw, beta=0.0):
 def sumsq(ws, dtype, x_ptr, n, acc, beta=0.0):
     w = ws.ensure(4096)
     _lib.call('tdg_sumsq', dtype, x_ptr, n, ptr(acc), beta, ptr(w), w.numel(), stream())
+
+
+def in_fwd(u, n, c, scale, shift, act, h, stats, leak=0.2, eps=1e-3, u_ptr=None, h_ptr=None):
+    """Instance norm + activation of n images of `u` into `h` (hem/ops/images.py:73-89)."""
+    _lib.call('tdg_instance_norm_fwd', u.dtype, u_ptr or u.ptr(), n, u.h * u.w, c, u.cs, ptr(scale), ptr(shift), eps, act, leak,
+              h_ptr or h.ptr(), h.cs, ptr(stats), stream())
+
+
+def in_bwd(ws, dh, u, n, c, scale, shift, stats, act, du, dscale, dshift, leak=0.2, beta=0.0, dh_ptr=None, u_ptr=None, du_ptr=None):
+    w = ws.ensure(n * 2 * c * 4)
+    _lib.call('tdg_instance_norm_bwd', dh.dtype, dh_ptr or dh.ptr(), dh.cs, u_ptr or u.ptr(), n, u.h * u.w, c, u.cs, ptr(scale),
+              ptr(shift), ptr(stats), act, leak, du_ptr or du.ptr(), ptr(dscale), ptr(dshift), beta, ptr(w), w.numel(), stream())
+
+
+def add_act(dtype, a_ptr, b_ptr, n_elems, out_ptr, act=ACT_NONE, leak=0.2):
+    """out = act(a + b) over n_elems elements of one layout."""
+    _lib.call('tdg_add_act', dtype, a_ptr, b_ptr, n_elems, act, leak, out_ptr, stream())

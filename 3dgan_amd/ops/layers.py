@@ -62,9 +62,10 @@ def _resolve_activation(act, layer_name):
 # ------------------------------------------------------------------------------ nets / scopes
 class LayerSpec:
     def __init__(self, kind, name, in_size, out_size, k=1, stride=1, use_bn=False, act=None,
-                 in_shape=None, out_shape=None, padding='SAME', init='xavier', dropout=0):
+                 in_shape=None, out_shape=None, padding='SAME', init='xavier', dropout=0, use_in=False):
         self.kind, self.name = kind, name
         self.dropout = dropout
+        self.use_in = bool(use_in)                   # instance norm (hem/ops/images.py:73-89) between the conv and the activation
         self.in_size, self.out_size, self.k, self.stride = in_size, out_size, k, stride
         self.use_bn, self.act = use_bn, _resolve_activation(act, name)
         self.in_shape, self.out_shape = in_shape, out_shape
@@ -72,7 +73,17 @@ class LayerSpec:
 
     def signature(self):
         return (self.kind, self.name, self.in_size, self.out_size, self.k, self.stride, self.use_bn,
-                self.act.code if self.act else 0, self.in_shape, self.out_shape)
+                self.act.code if self.act else 0, self.in_shape, self.out_shape, self.use_in)
+
+    @property
+    def normed(self):
+        """The layer's output passes through a normalisation before its activation (batch norm or instance norm)."""
+        return self.use_bn or self.use_in
+
+    @property
+    def n_bn(self):
+        """Batch-norm calls (= `BatchNorm[_i]` scopes) this layer makes: a residual block normalises both of its convs."""
+        return (2 if self.kind == 'residual' else 1) if self.use_bn else 0
 
     @property
     def filter_shape(self):
@@ -117,10 +128,11 @@ class Net:
         self._cur.append(spec)
         return spec
 
-    def bn_name(self, pass_idx, layer_idx):
-        """contrib batch_norm uniquifies its default scope per call: BatchNorm, BatchNorm_1, ..."""
-        per_pass = [i for i, l in enumerate(self.layers) if l.use_bn]
-        i = pass_idx * len(per_pass) + per_pass.index(layer_idx)
+    def bn_name(self, pass_idx, layer_idx, which=0):
+        """contrib batch_norm uniquifies its default scope per call: BatchNorm, BatchNorm_1, ...  (`which`: the second
+        batch norm of a residual block)."""
+        counts = [l.n_bn for l in self.layers]
+        i = pass_idx * sum(counts) + sum(counts[:layer_idx]) + which
         return '%s/BatchNorm%s/beta' % (self.name, '' if i == 0 else '_%d' % i)
 
     def var_name(self, layer, which):
@@ -208,11 +220,23 @@ def flatten(x, name=None):
     return reshape(x, [-1, n])
 
 
-def _reject_unsupported(name, dropout, renorm, instance_norm):
+def _reject_unsupported(name, dropout, renorm=False, instance_norm=False):
     if dropout:
         raise NotImplementedError('layer %s: dropout > 0 is not available in this build (SURVEY.md section 2 row 12)' % name)
-    if renorm or instance_norm:
-        raise NotImplementedError('layer %s: batch-renorm / instance-norm are out of scope (thesis samplers only)' % name)
+
+
+def _norm_flags(name, use_batch_norm, use_batch_renorm, use_instance_norm):
+    """(use_bn, use_in) of the gen-2 builders (hem/ops/layers.py:123-124,200-201).
+
+    `use_batch_renorm=True` is `tf.contrib.layers.batch_norm(renorm=True)` in training mode.  Its correction terms are
+    r = stddev / mixed_renorm_stddev and d = (mean - mixed_renorm_mean) / mixed_renorm_stddev, where the "mixed" moments
+    zero-debias the renorm moving averages: (renorm_x + (1 - renorm_x_weight) * batch_x).  Those averages and their weights
+    start at ZERO and are only advanced by the layer's update ops, which the reference never runs (SURVEY.md App. C-3:
+    the same `control_dependencies` defect that disables weight clipping) -- so the mixed moments ARE the batch moments,
+    r = 1 and d = 0 exactly, and batch renorm is batch norm: executed as such."""
+    if use_instance_norm and (use_batch_norm or use_batch_renorm):
+        raise NotImplementedError('layer %s: instance norm followed by batch norm is not built (no reference model does it)' % name)
+    return bool(use_batch_norm or use_batch_renorm), bool(use_instance_norm)
 
 
 def concat(xs, axis=-1):
@@ -249,7 +273,8 @@ def conv2d(x, input_size, output_size, filter_size=3, stride=1, init='xavier', u
            activation=None, reuse=False, name=None, padding='SAME', dropout=0, use_batch_renorm=False,
            use_instance_norm=False):
     """ops/layers.py:66-107 (gen-2: hem/ops/layers.py:70-135): tf.nn.conv2d + bias [+ batch_norm] [+ activation]."""
-    _reject_unsupported(name, dropout, use_batch_renorm, use_instance_norm)
+    _reject_unsupported(name, dropout)
+    use_batch_norm, use_in = _norm_flags(name, use_batch_norm, use_batch_renorm, use_instance_norm)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('conv2d %s: input has %d channels, expected %d' % (name, c, input_size))
@@ -258,9 +283,32 @@ def conv2d(x, input_size, output_size, filter_size=3, stride=1, init='xavier', u
     else:
         oh, ow = -(-(h - filter_size + 1) // stride), -(-(w - filter_size + 1) // stride)
     spec = LayerSpec('conv2d', name, input_size, output_size, filter_size, stride, use_batch_norm, activation,
-                     (h, w, c), (oh, ow, output_size), padding, init)
+                     (h, w, c), (oh, ow, output_size), padding, init, use_in=use_in)
     current_net().add(spec, reuse)
     return Sym((None, oh, ow, output_size), producer=spec)
+
+
+@add_arg_scope
+def residual(x, input_size, output_size, filter_size=3, stride=1, init='xavier', use_batch_norm=False, use_batch_renorm=False,
+             use_instance_norm=False, activation=None, reuse=False, dropout=0, padding='SAME', name=None):
+    """hem/ops/layers.py:215-320: a two-conv residual block.  conv A (`<name>A`) + bias -> `shortcut`; [batch norm],
+    activation; conv B (`<name>B`, output_size -> output_size) + bias, [batch norm]; + shortcut; activation.
+    Both convs use `stride`, so anything but stride 1 leaves the sum without matching shapes (TF raises there too)."""
+    _reject_unsupported(name, dropout)
+    if use_instance_norm:
+        # instance_norm_op(h, reuse=reuse, name=name) is called twice with the same variable names: with reuse=False the
+        # second get_variable raises in TF ("Variable ... already exists")
+        raise NotImplementedError('residual %s: use_instance_norm cannot be built in the reference either (duplicate variables)' % name)
+    use_bn, _ = _norm_flags(name, use_batch_norm, use_batch_renorm, False)
+    _, h, w, c = x.shape
+    if c != input_size:
+        raise ValueError('residual %s: input has %d channels, expected %d' % (name, c, input_size))
+    if stride != 1 or padding != 'SAME':
+        raise ValueError('residual %s: the shortcut sum needs stride 1 and SAME padding (both convs use the same stride)' % name)
+    spec = LayerSpec('residual', name, input_size, output_size, filter_size, 1, use_bn, activation,
+                     (h, w, c), (h, w, output_size), padding, init)
+    current_net().add(spec, reuse)
+    return Sym((None, h, w, output_size), producer=spec)
 
 
 @add_arg_scope
@@ -270,7 +318,7 @@ def deconv2d(x, input_size, output_size, filter_size=3, stride=2, init='xavier',
     """ops/layers.py:111-148 (gen-2: hem/ops/layers.py:138-211): tf.nn.conv2d_transpose; output = 2 x input unless an
     explicit gen-2 `output_shape` = (N, C, H, W) is given (hem/ops/layers.py:185-187, used with padding='VALID' by
     hem/models/paper_cgan.py:237-241).  As in TF the shape must be one the forward conv maps back onto the input."""
-    _reject_unsupported(name, 0, use_batch_renorm, use_instance_norm)        # dropout: recorded; the executor decides
+    use_batch_norm, use_in = _norm_flags(name, use_batch_norm, use_batch_renorm, use_instance_norm)     # (dropout: recorded; the executor decides)
     _, h, w, c = x.shape
     if c != input_size:
         raise ValueError('deconv2d %s: input has %d channels, expected %d' % (name, c, input_size))
@@ -288,6 +336,6 @@ def deconv2d(x, input_size, output_size, filter_size=3, stride=2, init='xavier',
         raise ValueError('deconv2d %s: a %s k%d s%d conv of a %dx%d output does not give the %dx%d input'
                          % (name, padding, filter_size, stride, oh, ow, h, w))
     spec = LayerSpec('deconv2d', name, input_size, output_size, filter_size, stride, use_batch_norm, activation,
-                     (h, w, c), (oh, ow, output_size), padding, init, dropout=dropout)
+                     (h, w, c), (oh, ow, output_size), padding, init, dropout=dropout, use_in=use_in)
     current_net().add(spec, reuse)
     return Sym((None, oh, ow, output_size), producer=spec)

@@ -184,6 +184,19 @@ size_t tdg_bn_workspace_bytes(int rows, int c);
 int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps,
                int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
                size_t workspace_bytes, void* stream);
+/* ---- instance norm of the gen-2 layer surface (hem/ops/images.py:73-89; `use_instance_norm=True`,
+ *      hem/ops/layers.py:123,200): per (image, channel) moments over the hw positions, biased variance, eps 1e-3,
+ *      learned per-channel scale (init 1) and shift (init 0); fused with the layer's activation.
+ *      stats [n][2][c] = (mu, rstd) are kept for the backward. */
+int tdg_instance_norm_fwd(int dtype, const void* u, int n, int hw, int c, int cs, const float* scale, const float* shift,
+                          float eps, int act, float leak, void* h, int h_cs, float* stats, void* stream);
+/* du = d/du of act(scale * xhat + shift) given dh; dscale / dshift = beta * old + sums over images and positions
+ * (deterministic); workspace >= n * 2 * c floats. */
+int tdg_instance_norm_bwd(int dtype, const void* dh, int dh_cs, const void* u, int n, int hw, int c, int cs, const float* scale,
+                          const float* shift, const float* stats, int act, float leak, void* du, float* dscale, float* dshift,
+                          float beta, void* workspace, size_t workspace_bytes, void* stream);
+/* out = act(a + b), flat, one layout: the shortcut sum of `residual` (hem/ops/layers.py:297-304); TDG_ACT_NONE = add */
+int tdg_add_act(int dtype, const void* a, const void* b, size_t n, int act, float leak, void* out, void* stream);
 /* tdg_bn_fwd with the batch statistics taken from TDG_COL_BN partials of the producing conv (pivot = that conv's
  * bias, may be NULL) instead of a pass over u: stats, then pre = (u - mean) * rstd + beta and h = act(pre). */
 int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,

@@ -283,3 +283,27 @@ def test_nyuv2_plugin_reads_png_records_crops_and_drops_sensor_gaps(tmp_path):
     ds = pkg('datasets')
     args.dataset, args.model = 'nyuv2', 'pix2pix'
     assert ds.get_dataset(args, sess)[1] == n
+
+
+def test_residual_and_norm_builders():
+    """hem/ops/layers.py:215-320 builder surface: variable names, batch-norm numbering, rejected forms."""
+    Lm, act = pkg('ops.layers'), pkg('ops.activations')
+    Lm.reset_graph()
+    x = Lm.placeholder((None, 8, 8, 3))
+    with Lm.variable_scope('generator') as net:
+        h = Lm.conv2d(x, 3, 4, use_batch_norm=True, stride=1, name='a')
+        h = Lm.residual(h, 4, 6, use_batch_renorm=True, activation=act.relu, name='r')
+        h = Lm.conv2d(h, 6, 2, use_instance_norm=True, stride=2, name='b')
+        h = Lm.deconv2d(h, 2, 2, use_batch_renorm=True, name='c')
+    assert h.shape == (None, 8, 8, 2)
+    kinds = [(l.kind, l.use_bn, l.use_in, l.n_bn) for l in net.layers]
+    assert kinds == [('conv2d', True, False, 1), ('residual', True, False, 2), ('conv2d', False, True, 0), ('deconv2d', True, False, 1)]
+    assert [net.bn_name(0, 0), net.bn_name(0, 1, 0), net.bn_name(0, 1, 1), net.bn_name(0, 3)] == \
+        ['generator/BatchNorm/beta', 'generator/BatchNorm_1/beta', 'generator/BatchNorm_2/beta', 'generator/BatchNorm_3/beta']
+    assert net.bn_name(1, 0) == 'generator/BatchNorm_4/beta'           # a second (reuse) pass continues the numbering
+    with pytest.raises(ValueError):
+        Lm.residual(h, 2, 2, stride=2, name='s')
+    with pytest.raises(NotImplementedError):
+        Lm.residual(h, 2, 2, use_instance_norm=True, name='t')
+    with pytest.raises(NotImplementedError):
+        Lm.conv2d(h, 2, 2, use_instance_norm=True, use_batch_norm=True, name='u')
