@@ -1986,6 +1986,182 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
   }
 }
 
+// ============================================================================================
+// Stride-2 backward-data / conv2d_transpose onto a thin big side whose (tap, channel) pairs fit 64 GEMM columns
+// (pix2pix: the decoder's last layer 128 -> 1 at 256 x 256, the critic's first layer gradient 64 -> 4): GEMM + col2im.
+//   P[pixel][(tap, c)] = sum_k y[pixel][k] * w[tap][c][k]      one 16-column MFMA tile per 16 (tap, c) pairs: no zero-stuffed
+//                                                              taps, no class padding (the fused-class kernel above spends
+//                                                              9 union taps x 16 columns on 4 taps x 4 columns here)
+//   x[2a + ph][2b + pw][c] = sum_{taps t of class (ph, pw)} P[(a + dh_t, b + dw_t)][(t, c)]
+// A workgroup owns TA x TW anchors of one image: its waves multiply the (TA + halo) x (TW + halo) small-side pixels -- A
+// fragments straight from global memory (each lane 16 bytes of one pixel; pixels outside the image are out-of-range
+// offsets = zeros), the filter [columns][KP] from LDS -- park P as f32 in LDS and then sum each output pixel's taps.
+// 40-50 KB of LDS: three workgroups per CU overlap one another's load and sum phases.   bf16 only.
+// ============================================================================================
+#define C2I_MAX_CLS_TAPS 9
+struct Col2imArgs {
+  const bf16_t* y;       // small side [n][SH][SW][Cs]
+  const bf16_t* w;       // packed filter [NT * 16][KP]: row = tap * C + c
+  bf16_t* x;             // big side [n][OH][OW][Cso]
+  const float* bias;
+  const bf16_t* mask_src;
+  int SH, SW, Cs;
+  int OH, OW, Cso, C;
+  int KP, NT, pitch, ke; // k padded to 32; 16-column tiles; f32 words per pixel of P in LDS; channels read per pixel
+  int TA, TW, ntr, ntc, HR, HC, dh_min, dw_min;
+  int p_off;             // LDS byte offset of P
+  int act, mask_mode, accumulate;
+  float leak;
+  int debug;                                // TDG_DEBUG_ABLATE (diagnostics): 1 = no global loads, 2 = no stores, 3 = no MFMA phase
+  int cls_ntaps[4];                         // class = 2 * (oy & 1) + (ox & 1)
+  int cls_tap[4][C2I_MAX_CLS_TAPS];         // (halo row offset << 16) | (halo column offset << 8) | filter tap
+  FastDiv fd_hc, fd_c, fd_ow2;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256) bwd_col2im_kernel(const Col2imArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
+  float* sP = reinterpret_cast<float*>(smem + a.p_off);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = blockIdx.x / a.ntc, ct = blockIdx.x - tile * a.ntc;
+  const int img = tile / a.ntr, rt = tile - img * a.ntr;
+  const int a0 = rt * a.TA, c0 = ct * a.TW;
+  const int npx = a.HR * a.HC, ntile = (npx + 15) / 16;
+  // the class tap table (a per-lane index into kernel arguments would be a global load per tap) and the filter: straight copies
+  int* sTab = reinterpret_cast<int*>(smem + a.p_off - 256);
+  if (tid < 4) sTab[tid] = a.cls_ntaps[tid];
+  if (tid < 4 * C2I_MAX_CLS_TAPS) sTab[4 + tid] = a.cls_tap[tid / C2I_MAX_CLS_TAPS][tid % C2I_MAX_CLS_TAPS];
+  {
+    const int nv = NT * 16 * a.KP / 8;
+    const uint4* src = reinterpret_cast<const uint4*>(a.w);
+    uint4* dst = reinterpret_cast<uint4*>(sW);
+    for (int i = tid; i < nv; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.y + (size_t)img * a.SH * a.SW * a.Cs, (unsigned)(a.SH * a.SW * a.Cs * 2));
+  const int r16 = lane & 15, q = lane >> 4;
+  const int kcn = a.KP / 32;
+  const bf16_t* wrow = sW + r16 * a.KP + q * 8;
+  for (int t0 = wave; t0 < (a.debug == 3 ? 0 : ntile); t0 += 8) {
+    // two 16-pixel tiles share every filter fragment
+    unsigned off[2];
+    int hp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int t = t0 + 4 * h;
+      hp[h] = t * 16 + r16;
+      const int hr = (int)fd_div((unsigned)hp[h], a.fd_hc), hc = hp[h] - hr * a.HC;
+      const int r = a0 + hr + a.dh_min, c = c0 + hc + a.dw_min;
+      const bool ok = t < ntile && hp[h] < npx && (unsigned)r < (unsigned)a.SH && (unsigned)c < (unsigned)a.SW;
+      off[h] = (ok && a.debug != 1) ? (unsigned)(((r * a.SW + c) * a.Cs + q * 8) * 2) : OOB_OFFSET;
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[h][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kc = 0; kc < kcn; ++kc) {
+      const bool kok = kc * 32 + q * 8 < a.ke;                 // (KP > ke: the next pixel's channels must not meet the zero filter rows as NaN)
+      const bf16x8 f0 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rY, (off[0] == OOB_OFFSET || !kok) ? OOB_OFFSET : off[0] + kc * 64, 0, 0));
+      const bf16x8 f1 = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rY, (off[1] == OOB_OFFSET || !kok) ? OOB_OFFSET : off[1] + kc * 64, 0, 0));
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 fw = *reinterpret_cast<const bf16x8*>(wrow + n * 16 * a.KP + kc * 32);
+        acc[0][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, f0, acc[0][n], 0, 0, 0);
+        acc[1][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, f1, acc[1][n], 0, 0, 0);
+      }
+    }
+    // lane holds columns 16n + 4q .. + 3 of its pixel
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      if (t0 + 4 * h < ntile && hp[h] < npx) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) *reinterpret_cast<f32x4*>(sP + (size_t)hp[h] * a.pitch + n * 16 + q * 4) = acc[h][n];
+      }
+  }
+  __syncthreads();
+  // ---- col2im: each output value of the tile is the sum of its class's taps ---------------------------------------
+  const int ow2 = 2 * a.TW, nout = 4 * a.TA * a.TW * a.C;
+  for (int o = tid; o < nout; o += 256) {
+    const int pix = (int)fd_div((unsigned)o, a.fd_c), c = o - pix * a.C;
+    const int oyl = (int)fd_div((unsigned)pix, a.fd_ow2), oxl = pix - oyl * ow2;
+    const int oy = 2 * a0 + oyl, ox = 2 * c0 + oxl;
+    if (oy >= a.OH || ox >= a.OW) continue;
+    const int cls = 2 * (oyl & 1) + (oxl & 1), al = oyl >> 1, bl = oxl >> 1;
+    float v = 0.f;
+    const int nt = sTab[cls];
+    for (int t = 0; t < nt; ++t) {
+      const int pk = sTab[4 + cls * C2I_MAX_CLS_TAPS + t];
+      v += sP[(size_t)((al + (pk >> 16)) * a.HC + bl + ((pk >> 8) & 0xff)) * a.pitch + (pk & 0xff) * a.C + c];
+    }
+    const size_t g = (((size_t)img * a.OH + oy) * a.OW + ox) * a.Cso + c;
+    v = apply_act(v + (a.bias ? a.bias[c] : 0.f), a.act, a.leak);
+    if (a.accumulate) v += (float)a.x[g];
+    if (a.mask_mode != TDG_MASK_NONE) v *= mask_factor((float)a.mask_src[g], a.mask_mode, a.leak);
+    if (a.debug != 2 || v == 12345.f) a.x[g] = (bf16_t)v;
+  }
+}
+
+// ============================================================================================
+// Forward conv to ONE output channel (the PatchGAN critic's logits: 512 -> 1, 4x4, M = images x 8 x 8): a dot product
+// per output pixel.  The 128 x 16 MFMA tile spends a 128-step K loop per workgroup on 64 workgroups (0.11 ms for 34 MB
+// of input); here one wave owns one output pixel, lanes take 16-byte channel chunks of every tap (padding taps are
+// out-of-range offsets), the packed filter row is read the same way.
+// ============================================================================================
+struct ConvN1Args {
+  const void* x;
+  const void* w;         // packed forward filter: one row [ntaps][C] in the launch's tap order
+  void* y;
+  const float* bias;
+  unsigned x_bytes, w_bytes;
+  int SH, SW, Cs, C, OH, OW, Cso, stride, ntaps, M;
+  int act;
+  float leak;
+  int tap[IG_MAX_TAPS];
+  FastDiv fd_ohw, fd_ow;
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) conv_n1_fwd_kernel(const ConvN1Args a) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + wave;
+  if (m >= a.M) return;
+  const int n = (int)fd_div((unsigned)m, a.fd_ohw), rem = m - n * a.OH * a.OW;
+  const int oy = (int)fd_div((unsigned)rem, a.fd_ow), ox = rem - oy * a.OW;
+  const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.x, a.x_bytes);
+  const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w, a.w_bytes);
+  const int cv = a.C / VEC;
+  float s = 0.f;
+#pragma unroll 4
+  for (int t = 0; t < a.ntaps; ++t) {
+    const int pk = a.tap[t];
+    const int ih = oy * a.stride + tap_dh(pk), iw = ox * a.stride + tap_dw(pk);
+    const bool ok = (unsigned)ih < (unsigned)a.SH && (unsigned)iw < (unsigned)a.SW;
+    const unsigned xb = (unsigned)(((n * a.SH + ih) * a.SW + iw) * a.Cs) * (unsigned)sizeof(T);
+    const unsigned wb = (unsigned)(t * a.C) * (unsigned)sizeof(T);
+    for (int ch = lane; ch < cv; ch += 64) {
+      const auto xv = __builtin_amdgcn_raw_buffer_load_b128(rX, ok ? xb + ch * 16u : OOB_OFFSET, 0, 0);
+      const auto wv = __builtin_amdgcn_raw_buffer_load_b128(rW, wb + ch * 16u, 0, 0);
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 xf = __builtin_bit_cast(bf16x8, xv), wf = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)xf[e] * (float)wf[e];
+      } else {
+        const f32x4 xf = __builtin_bit_cast(f32x4, xv), wf = __builtin_bit_cast(f32x4, wv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s += xf[e] * wf[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0)
+    static_cast<T*>(a.y)[(size_t)m * a.Cso] = from_f32<T>(apply_act(s + (a.bias ? a.bias[0] : 0.f), a.act, a.leak));
+}
+
 // merged filter of bwd_fused_kernel from the f32 master [kh][kw][c][k]
 struct FusedPackArgs {
   const float* w;
@@ -2553,6 +2729,64 @@ int plan_bwd_classes(const TdgConvDesc* d, BwdClassPlan* cls) {
   return nc;
 }
 
+// ---- GEMM + col2im backward-data (bwd_col2im_kernel): when it applies and its geometry ---------------------------------
+struct Col2imPlan {
+  int ke, KP, NT, pitch, TA, TW, ntr, ntc, HR, HC, dh_min, dw_min, GH, GW, p_off;
+  size_t w_bytes, lds;
+};
+
+bool plan_bwd_col2im(const TdgConvDesc* d, Col2imPlan* f) {
+  static const int enabled = getenv("TDG_COL2IM") ? atoi(getenv("TDG_COL2IM")) : 1;   // diagnostics: 0 = fused-class / per-class kernels
+  if (!enabled || d->dtype != TDG_BF16 || d->stride != 2) return false;
+  if (d->kh < 2 || d->kw < 2 || d->kh > 6 || d->kw > 6) return false;
+  const int ncol = d->kh * d->kw * d->c;
+  if (ncol > 64) return false;
+  const int ke = eff_channels(d->k, d->ks, 8);
+  if (!ke) return false;
+  BwdClassPlan cls[IG_MAX_CLASSES];
+  const int nc = plan_bwd_classes(d, cls);
+  if (nc != 4) return false;
+  int dh_lo = 1 << 20, dh_hi = -(1 << 20), dw_lo = 1 << 20, dw_hi = -(1 << 20);
+  for (int i = 0; i < nc; ++i) {
+    if (cls[i].ntaps > C2I_MAX_CLS_TAPS || cls[i].ntaps == 0) return false;
+    for (int t = 0; t < cls[i].ntaps; ++t) {
+      dh_lo = cls[i].dh[t] < dh_lo ? cls[i].dh[t] : dh_lo;
+      dh_hi = cls[i].dh[t] > dh_hi ? cls[i].dh[t] : dh_hi;
+      dw_lo = cls[i].dw[t] < dw_lo ? cls[i].dw[t] : dw_lo;
+      dw_hi = cls[i].dw[t] > dw_hi ? cls[i].dw[t] : dw_hi;
+    }
+  }
+  const int nhm = dh_hi - dh_lo + 1, nwm = dw_hi - dw_lo + 1;
+  f->dh_min = dh_lo;
+  f->dw_min = dw_lo;
+  f->ke = ke;
+  f->KP = (int)tdg_round_up(ke, 32);
+  f->NT = tdg_ceil_div(ncol, 16);
+  f->pitch = f->NT == 1 ? 16 : f->NT * 16 + 4;
+  f->GH = (d->h + 1) / 2;
+  f->GW = (d->w + 1) / 2;
+  f->w_bytes = (size_t)f->NT * 16 * f->KP * 2;
+  f->p_off = (int)tdg_round_up((long long)f->w_bytes, 256) + 256;       // filter | class tap table (256 bytes) | P
+  // measured on pix2pix d8 (128 -> 1, 64 x 256 x 256): 48 KB 0.092 ms, 32 KB 0.081 ms, 16-24 KB 0.085 ms (more workgroups per CU
+  // overlap the load / multiply / sum phases, smaller tiles re-read more halo); m1's input gradient (4 column tiles): 48 KB best
+  static const int budget_kb = getenv("TDG_C2I_KB") ? atoi(getenv("TDG_C2I_KB")) : 0;   // diagnostics
+  const size_t budget = (size_t)(budget_kb ? budget_kb : (f->NT == 1 ? 32 : 48)) * 1024;
+  int ta = f->GH < 16 ? f->GH : 16, tw = f->GW < 32 ? f->GW : 32;
+  auto need = [&](int a_, int w_) { return (size_t)f->p_off + (size_t)(a_ + nhm - 1) * (w_ + nwm - 1) * f->pitch * 4; };
+  while (need(ta, tw) > budget && ta > 4) ta = (ta + 1) / 2;
+  while (need(ta, tw) > budget && tw > 4) tw = (tw + 1) / 2;
+  if (need(ta, tw) > budget) return false;
+  f->ntr = tdg_ceil_div(f->GH, ta);
+  f->TA = tdg_ceil_div(f->GH, f->ntr);
+  f->ntc = tdg_ceil_div(f->GW, tw);
+  f->TW = tdg_ceil_div(f->GW, f->ntc);
+  f->HR = f->TA + nhm - 1;
+  f->HC = f->TW + nwm - 1;
+  if (f->HR > 255 || f->HC > 255) return false;
+  f->lds = need(f->TA, f->TW);
+  return true;
+}
+
 // ---- fused-class backward-data (bwd_fused_kernel): when it applies and its geometry ---------------------------
 struct FusedPlan {
   int nhm, nwm, dh_min, dw_min, ntap, ke, KP, PP, wpitch, TA, ntr, TW, ntc, GH, GW, y_off;
@@ -2563,6 +2797,8 @@ bool plan_bwd_fused(const TdgConvDesc* d, FusedPlan* f) {
   static const int enabled = getenv("TDG_FUSE") ? atoi(getenv("TDG_FUSE")) : 1;   // diagnostics: 0 = one launch-z per class
   if (!enabled || d->dtype != TDG_BF16 || d->stride != 2 || 4 * d->c > 16) return false;
   if (d->kh < 2 || d->kw < 2) return false;                  // every class needs a tap
+  Col2imPlan cp;
+  if (plan_bwd_col2im(d, &cp)) return false;                 // few (tap, channel) columns: GEMM + col2im
   const int ke = eff_channels(d->k, d->ks, 8);
   if (!ke) return false;
   BwdClassPlan cls[IG_MAX_CLASSES];
@@ -2666,6 +2902,8 @@ size_t tdg_packed_filter_bwd_bytes(const TdgConvDesc* d) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es, bke = IG_BKB / es;
   int ke = eff_channels(d->k, d->ks, vec);
   if (!ke) ke = d->k;
+  Col2imPlan cp;
+  if (plan_bwd_col2im(d, &cp)) return cp.w_bytes;
   FusedPlan fp;
   if (plan_bwd_fused(d, &fp)) return fp.w_bytes;
   BwdClassPlan cls[IG_MAX_CLASSES];
@@ -2723,6 +2961,21 @@ static int build_pack_bwd(const TdgConvDesc* d, const float* w, void* packed, Pa
   return n;
 }
 
+// bwd_col2im_kernel's filter [tap * C + c][KP] is the master [kh][kw][c][k] cast row by row
+static void build_pack_col2im(const TdgConvDesc* d, const Col2imPlan& cp, const float* w, void* packed, PackArgs* a) {
+  a->w = w;
+  a->out = packed;
+  a->rows = d->kh * d->kw * d->c;
+  a->ntaps = 1;
+  a->C = d->k;
+  a->Ceff = cp.ke;
+  a->Kp = cp.KP;
+  a->stride_tap = 0;
+  a->stride_row = d->k;
+  a->stride_ch = 1;
+  a->tap_ids[0] = 0;
+}
+
 static int launch_pack_one(const PackArgs& a, int dtype, hipStream_t s) {
   dim3 grid(tdg_ceil_div(a.Kp, PACK_TK), tdg_ceil_div(a.rows, 32));
   if (dtype == TDG_BF16)
@@ -2769,6 +3022,12 @@ int tdg_pack_filter_bwd(const TdgConvDesc* d, const float* w, void* packed, void
   int rc = validate_desc(d, "tdg_pack_filter_bwd");
   if (rc) return rc;
   TDG_CHECK_ARG(w && packed, "tdg_pack_filter_bwd: null pointer");
+  Col2imPlan cp;
+  if (plan_bwd_col2im(d, &cp)) {
+    PackArgs a;
+    build_pack_col2im(d, cp, w, packed, &a);
+    return launch_pack_one(a, d->dtype, (hipStream_t)stream);
+  }
   FusedPlan fp;
   if (plan_bwd_fused(d, &fp)) return launch_pack_fused(d, fp, w, packed, (hipStream_t)stream);
   PackArgs a[IG_MAX_CLASSES];
@@ -2826,7 +3085,13 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
     }
     if (jobs[j].packed_bwd) {
       FusedPlan fp;
-      if (plan_bwd_fused(d, &fp)) {
+      Col2imPlan cp;
+      if (plan_bwd_col2im(d, &cp)) {
+        PackArgs a;
+        build_pack_col2im(d, cp, jobs[j].w, jobs[j].packed_bwd, &a);
+        rc = push(a);
+        if (rc) return rc;
+      } else if (plan_bwd_fused(d, &fp)) {
         rc = launch_pack_fused(d, fp, jobs[j].w, jobs[j].packed_bwd, (hipStream_t)stream);
         if (rc) return rc;
       } else {
@@ -2914,6 +3179,37 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
     TDG_HIP_LAUNCH_CHECK("thin_fwd");
     return TDG_OK;
   }
+  static const int n1_enabled = getenv("TDG_CONVN1") ? atoi(getenv("TDG_CONVN1")) : 1;   // diagnostics: 0 = the 128 x 16 MFMA tile
+  if (n1_enabled && d->k == 1 && veca && d->kh * d->kw <= IG_MAX_TAPS && (long long)n_images * d->oh * d->ow >= 1024 &&
+      !(epi && (epi->accumulate || epi->mask_mode != TDG_MASK_NONE))) {
+    if (epi && epi->col_nblk_out) *epi->col_nblk_out = 0;       // no column partials from this kernel: the host runs its own pass
+    ConvN1Args f;
+    memset(&f, 0, sizeof(f));
+    f.x = x; f.w = wp; f.y = y;
+    f.bias = epi ? epi->bias : nullptr;
+    f.act = epi ? epi->act : TDG_ACT_NONE;
+    f.leak = epi ? epi->leak : 0.f;
+    f.x_bytes = (unsigned)((long long)n_images * d->h * d->w * d->cs * es);
+    f.w_bytes = (unsigned)tdg_packed_filter_fwd_bytes(d);
+    f.SH = d->h; f.SW = d->w; f.Cs = d->cs; f.C = C; f.OH = d->oh; f.OW = d->ow; f.Cso = d->ks; f.stride = d->stride;
+    f.ntaps = d->kh * d->kw;
+    f.M = n_images * d->oh * d->ow;
+    int ord[IG_MAX_TAPS];
+    fwd_tap_order(d, ord);
+    for (int t = 0; t < f.ntaps; ++t) f.tap[t] = pack_tap(ord[t] / d->kw - d->pad_t, ord[t] % d->kw - d->pad_l);
+    f.fd_ohw = make_fastdiv(d->oh * d->ow);
+    f.fd_ow = make_fastdiv(d->ow);
+    const char* name = d->dtype == TDG_BF16 ? "conv_n1_fwd_kernel<bf16>" : "conv_n1_fwd_kernel<f32>";
+    tdg_note_kernel(name);
+    tdg_timing_start(name, conv_flops(d, n_images), (hipStream_t)stream);
+    if (d->dtype == TDG_BF16)
+      hipLaunchKernelGGL(conv_n1_fwd_kernel<bf16_t>, dim3(tdg_ceil_div(f.M, 4)), dim3(256), 0, (hipStream_t)stream, f);
+    else
+      hipLaunchKernelGGL(conv_n1_fwd_kernel<float>, dim3(tdg_ceil_div(f.M, 4)), dim3(256), 0, (hipStream_t)stream, f);
+    tdg_timing_stop((hipStream_t)stream);
+    TDG_HIP_LAUNCH_CHECK("conv_n1_fwd");
+    return TDG_OK;
+  }
   IgArgs a;
   memset(&a, 0, sizeof(a));
   a.src = x;
@@ -2961,6 +3257,49 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
   const bool veca = ke != 0;
   const int C = veca ? ke : d->k;
   TDG_CHECK_ARG(!veca || ((uintptr_t)y & 15) == 0, "tdg_conv2d_bwd_data: y must be 16-byte aligned (channel stride allows the vector gather)");
+  Col2imPlan cp;
+  if (plan_bwd_col2im(d, &cp)) {
+    Col2imArgs f;
+    memset(&f, 0, sizeof(f));
+    f.y = static_cast<const bf16_t*>(y);
+    f.w = static_cast<const bf16_t*>(wp);
+    f.x = static_cast<bf16_t*>(x);
+    f.bias = epi ? epi->bias : nullptr;
+    f.act = epi ? epi->act : TDG_ACT_NONE;
+    f.leak = epi ? epi->leak : 0.f;
+    f.mask_mode = epi ? epi->mask_mode : TDG_MASK_NONE;
+    f.mask_src = f.mask_mode != TDG_MASK_NONE ? static_cast<const bf16_t*>(epi->mask_src) : nullptr;
+    f.accumulate = epi ? epi->accumulate : 0;
+    f.SH = d->oh; f.SW = d->ow; f.Cs = d->ks;
+    f.OH = d->h; f.OW = d->w; f.Cso = d->cs; f.C = d->c;
+    f.KP = cp.KP; f.NT = cp.NT; f.pitch = cp.pitch; f.ke = cp.ke;
+    f.TA = cp.TA; f.TW = cp.TW; f.ntr = cp.ntr; f.ntc = cp.ntc; f.HR = cp.HR; f.HC = cp.HC; f.dh_min = cp.dh_min; f.dw_min = cp.dw_min;
+    f.p_off = cp.p_off;
+    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+    BwdClassPlan plan[IG_MAX_CLASSES];
+    plan_bwd_classes(d, plan);
+    for (int i = 0; i < 4; ++i) {
+      const int ci = 2 * plan[i].oh0 + plan[i].ow0;
+      f.cls_ntaps[ci] = plan[i].ntaps;
+      for (int t = 0; t < plan[i].ntaps; ++t)
+        f.cls_tap[ci][t] = ((plan[i].dh[t] - cp.dh_min) << 16) | ((plan[i].dw[t] - cp.dw_min) << 8) | plan[i].tap_ids[t];
+    }
+    f.fd_hc = make_fastdiv(cp.HC);
+    f.fd_c = make_fastdiv(d->c);
+    f.fd_ow2 = make_fastdiv(2 * cp.TW);
+    tdg_note_kernel("bwd_col2im_kernel<bf16>");
+    tdg_timing_start("bwd_col2im_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
+    const dim3 grid(n_images * cp.ntr * cp.ntc);
+    switch (cp.NT) {
+      case 1: hipLaunchKernelGGL(bwd_col2im_kernel<1>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+      case 2: hipLaunchKernelGGL(bwd_col2im_kernel<2>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+      case 3: hipLaunchKernelGGL(bwd_col2im_kernel<3>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+      default: hipLaunchKernelGGL(bwd_col2im_kernel<4>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+    }
+    tdg_timing_stop((hipStream_t)stream);
+    TDG_HIP_LAUNCH_CHECK("bwd_col2im");
+    return TDG_OK;
+  }
   FusedPlan fp;
   if (plan_bwd_fused(d, &fp)) {
     FusedBwdArgs f;

@@ -48,6 +48,14 @@ CONV_CASES = [
     (1, 256, 256, 1, 128, 4, 2),   # pix2pix d8 at full width: fused-class backward-data with COLUMN tiles (128 anchors x 128 channels)
     (80, 16, 16, 8, 400, 5, 2),    # 400 columns on an under-filled grid: 128 x 112 tiles (four column tiles, the last one 64 wide);
                                    # the smaller 400-column cases above take the 64 x 112 tile
+    # GEMM + col2im backward-data ((tap, channel) pairs <= 64 columns; the k4 / one-channel cases above take it too)
+    (3, 7, 9, 1, 24, 5, 2),        # 25 columns (two MFMA column tiles), odd sizes: ragged parity classes and halo
+    (2, 9, 11, 2, 16, 4, 2),       # 32 columns, odd sizes
+    (3, 30, 30, 4, 72, 3, 2),      # k3: 36 columns (three column tiles), K = 72 padded to 96
+    (2, 70, 40, 1, 32, 5, 2),      # several row tiles per image (35 anchor rows)
+    # one output channel: the wave-per-pixel forward kernel (M >= 1024)
+    (16, 16, 16, 64, 1, 4, 2),     # pix2pix m5 geometry at 64 channels
+    (5, 15, 17, 24, 1, 3, 1),      # stride 1, odd sizes, C / 8 = 3 chunks per tap
 ]
 
 

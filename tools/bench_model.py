@@ -52,6 +52,9 @@ def main():
     print('conv GEMM kernels: %.2f ms per call' % tot)
     for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         print('  %-44s %4d launches %8.3f ms %7.1f TF' % (k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12 if v[1] else 0))
+    if os.environ.get('TDG_LIST_LAUNCHES'):
+        for i, (name, ms, fl) in enumerate(rec):
+            print('  #%03d %-44s %8.4f ms %8.2f GFLOP %7.1f TF' % (i, name, ms, fl / 1e9, fl / (ms * 1e-3) / 1e12 if ms else 0))
 
 
 if __name__ == '__main__':
