@@ -2214,8 +2214,13 @@ struct ThinFwdArgs {
   FastDiv fd_ow, fd_c, fd_pw;
 };
 
+// NC = 208: 2 x 2 waves of 64 pixels x 112 columns (the GAN critic's c1: N = 200);  NC = 64: 4 x 1 waves of 32 pixels x 64
+// columns (pix2pix e1 / m1, N = 64: the 128 x 64 implicit-GEMM tile spent its life in ring prologue and epilogue latency:
+// 1.5 TB/s of output writes)
+template <int NC>
 __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
-  constexpr int BNL = 224, TM = 4, TN = 7;
+  constexpr int BNL = NC == 208 ? 224 : NC, TM = NC == 208 ? 4 : 2, TN = NC == 208 ? 7 : NC / 16;
+  constexpr int WROWS = TM * 16;                               // pixels per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* sW = reinterpret_cast<bf16_t*>(smem);
   unsigned short* sP = reinterpret_cast<unsigned short*>(smem + a.y_off);          // patch [PH][PW][4]
@@ -2223,7 +2228,7 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r16 = lane & 15, q = lane >> 4;
   const int tile_n = blockIdx.x % a.ntiles_n, tile_m = blockIdx.x / a.ntiles_n;
   const int img = tile_m / a.tiles_per_image, rt = tile_m - img * a.tiles_per_image;
-  const int oy0 = rt * a.TH, n0 = tile_n * 208;
+  const int oy0 = rt * a.TH, n0 = tile_n * NC;
   const int npix = min(a.TH, a.OH - oy0) * a.OW;
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0;
   TDG_STAMP(ts0);
@@ -2260,7 +2265,7 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   __syncthreads();
   TDG_STAMP(ts1);
 
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NC == 208 ? wave >> 1 : wave, wn = NC == 208 ? wave & 1 : 0;
   // the wave's bias pieces, loaded now so that their latency hides behind the MFMA loop (N % 4 == 0: plan_fwd_thin)
   f32x4 bvs[TN];
 #pragma unroll
@@ -2278,7 +2283,7 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   const int zero_off = a.PH * a.PW * 4;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    int p = wm * 64 + i * 16 + r16;
+    int p = wm * WROWS + i * 16 + r16;
     p = p < npix ? p : 0;
     const int oy = (int)fd_div((unsigned)p, a.fd_ow), ox = p - oy * a.OW;
     pbase[i] = (oy * a.stride * a.PW + ox * a.stride) * 4;
@@ -2288,7 +2293,7 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const bf16_t* wrow = sW + (size_t)(wn * 112 + r16) * a.WP + q * 8;
+  const bf16_t* wrow = sW + (size_t)(wn * TN * 16 + r16) * a.WP + q * 8;
 
   for (int ks = 0; ks < (a.debug == 8 ? 0 : a.Kp / 32); ++ks) {
     // this lane's 8 k offsets of the step (the same for every pixel)
@@ -2324,20 +2329,20 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
   __syncthreads();                                        // every wave is done with sW / sP: reuse LDS as the staging tile
 
   // ---- epilogue: bias + activation into an LDS tile, then whole 16-byte chunks of pixel rows to HBM ----------------
-  constexpr int PE = 208 * 2 + 16, CPR = 208 * 2 / 16;
+  constexpr int PE = NC * 2 + 16, CPR = NC * 2 / 16;
   char* sE = smem;
   dispatch_act(a.act, [&](auto tag) {
     constexpr int ACT = decltype(tag)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = (wn * TN + j) * 16 + q * 4;
-      if (col >= 208) continue;
+      if (col >= NC) continue;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         f32x4 v = acc[i][j] + bvs[j];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e], a.act, a.leak);
-        *reinterpret_cast<bf16x4*>(sE + (wm * 64 + i * 16 + r16) * PE + col * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(sE + (wm * WROWS + i * 16 + r16) * PE + col * 2) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
       }
     }
   });
@@ -2378,14 +2383,15 @@ struct ThinPackArgs {
   const float* w;
   bf16_t* out;
   int C, N, taps, Kp, WP, rows;
+  int tile_rows, tile_cols;   // filter rows staged per column tile / output columns of a tile (224 / 208 or 64 / 64)
 };
 __global__ void __launch_bounds__(256) pack_thin_kernel(const ThinPackArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.rows * a.WP) return;
   const int r = i / a.WP, k = i - r * a.WP;
-  const int n = (r / 224) * 208 + (r % 224);              // row r of tile r/224 is output column tile*208 + r%224
+  const int n = (r / a.tile_rows) * a.tile_cols + (r % a.tile_rows);     // row r of tile t = r / tile_rows is output column t * tile_cols + r % tile_rows
   float v = 0.f;
-  if ((r % 224) < 208 && n < a.N && k < a.taps * a.C) {
+  if ((r % a.tile_rows) < a.tile_cols && n < a.N && k < a.taps * a.C) {
     const int tap = k / a.C, c = k - tap * a.C;
     v = a.w[((size_t)tap * a.C + c) * a.N + n];
   }
@@ -2854,30 +2860,37 @@ bool plan_bwd_fused(const TdgConvDesc* d, FusedPlan* f) {
 
 // ---- thin-input forward conv (thin_fwd_kernel): when it applies and its geometry ------------------------------------
 struct ThinPlan {
+  int NC;                 // output columns per tile: 208 or 64
   int Kp, WP, TH, tiles_per_image, ntiles_n, PH, PW, y_off, k_off, rows;
   size_t w_bytes, lds;
 };
 
 bool plan_fwd_thin(const TdgConvDesc* d, ThinPlan* t) {
-  static const int enabled = getenv("TDG_THIN") ? atoi(getenv("TDG_THIN")) : 1;   // diagnostics: 0 = implicit-GEMM kernels
+  static const int enabled = getenv("TDG_THIN") ? atoi(getenv("TDG_THIN")) : 1;   // diagnostics: 0 = implicit-GEMM kernels, 2 = only the 208-column form
   if (!enabled || d->dtype != TDG_BF16 || d->c > 4 || d->cs < 4 || (d->cs & 3) || (d->k & 7) || (d->ks & 7)) return false;
-  if (d->ow > TH_PIX || d->k < 160) return false;              // narrow outputs waste the 208-column tile: implicit GEMM
+  if (d->ow > TH_PIX) return false;
+  // 208-column tiles for wide outputs; 64-column tiles for 32 .. 128 output channels on large images (narrow outputs on small
+  // images stay with the implicit-GEMM kernels: their launches are too small for the difference to show)
+  if (d->k >= 160) t->NC = 208;
+  else if (enabled != 2 && d->k >= 32 && d->k <= 128 && d->oh * d->ow >= 4096) t->NC = 64;
+  else return false;
+  const int tile_rows = t->NC == 208 ? 224 : 64;
   t->Kp = (int)tdg_round_up((long long)d->kh * d->kw * d->c, 32);
   if (t->Kp > 256) return false;
   t->WP = ((t->Kp / 8) & 1) ? t->Kp : t->Kp + 8;               // odd number of 16-byte chunks per filter row
   t->TH = TH_PIX / d->ow;
   if (t->TH > d->oh) t->TH = d->oh;
   t->tiles_per_image = tdg_ceil_div(d->oh, t->TH);
-  t->ntiles_n = tdg_ceil_div(d->k, 208);
+  t->ntiles_n = tdg_ceil_div(d->k, t->NC);
   t->PH = (t->TH - 1) * d->stride + d->kh;
   t->PW = (d->ow - 1) * d->stride + d->kw;
   if ((long long)t->PH * t->PW * 4 + 8 > 0xfff0) return false; // 16-bit patch offsets
-  t->rows = t->ntiles_n * 224;
+  t->rows = t->ntiles_n * tile_rows;
   t->w_bytes = (size_t)t->rows * t->WP * 2;
-  t->y_off = (int)tdg_round_up((long long)224 * t->WP * 2, 1024);               // + the zero-filled tail of the last filter DMA
+  t->y_off = (int)tdg_round_up((long long)tile_rows * t->WP * 2, 1024);         // + the zero-filled tail of the last filter DMA
   t->k_off = t->y_off + (int)tdg_round_up(((long long)t->PH * t->PW * 2 + 4) * 4, 256);   // + the tail of the last patch DMA
   const size_t main = (size_t)t->k_off + (size_t)t->Kp * 2 + 16;
-  const size_t epi = (size_t)TH_PIX * (208 * 2 + 16);
+  const size_t epi = (size_t)TH_PIX * (t->NC * 2 + 16);
   t->lds = main > epi ? main : epi;
   return t->lds <= 80 * 1024;                                  // two workgroups per CU
 }
@@ -3002,6 +3015,7 @@ static int launch_pack_thin(const TdgConvDesc* d, const ThinPlan& tp, const floa
   a.w = w;
   a.out = static_cast<bf16_t*>(packed);
   a.C = d->c; a.N = d->k; a.taps = d->kh * d->kw; a.Kp = tp.Kp; a.WP = tp.WP; a.rows = tp.rows;
+  a.tile_rows = tp.NC == 208 ? 224 : 64; a.tile_cols = tp.NC;
   hipLaunchKernelGGL(pack_thin_kernel, dim3(tdg_ceil_div((long long)tp.rows * tp.WP, 256)), dim3(256), 0, s, a);
   TDG_HIP_LAUNCH_CHECK("pack_filter_fwd(thin)");
   return TDG_OK;
@@ -3169,12 +3183,18 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
 #endif
     static bool attr_set = false;
     if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<208>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
       attr_set = true;
     }
-    tdg_note_kernel("thin_fwd_kernel<bf16>");
-    tdg_timing_start("thin_fwd_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
-    hipLaunchKernelGGL(thin_fwd_kernel, dim3(n_images * tp.tiles_per_image * tp.ntiles_n), dim3(256), tp.lds, (hipStream_t)stream, f);
+    const char* kname = tp.NC == 208 ? "thin_fwd_kernel<bf16>" : "thin_fwd_kernel<bf16,64>";
+    tdg_note_kernel(kname);
+    tdg_timing_start(kname, conv_flops(d, n_images), (hipStream_t)stream);
+    const dim3 tgrid(n_images * tp.tiles_per_image * tp.ntiles_n);
+    if (tp.NC == 208)
+      hipLaunchKernelGGL(thin_fwd_kernel<208>, tgrid, dim3(256), tp.lds, (hipStream_t)stream, f);
+    else
+      hipLaunchKernelGGL(thin_fwd_kernel<64>, tgrid, dim3(256), tp.lds, (hipStream_t)stream, f);
     tdg_timing_stop((hipStream_t)stream);
     TDG_HIP_LAUNCH_CHECK("thin_fwd");
     return TDG_OK;

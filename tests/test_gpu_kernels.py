@@ -53,6 +53,11 @@ CONV_CASES = [
     (2, 9, 11, 2, 16, 4, 2),       # 32 columns, odd sizes
     (3, 30, 30, 4, 72, 3, 2),      # k3: 36 columns (three column tiles), K = 72 padded to 96
     (2, 70, 40, 1, 32, 5, 2),      # several row tiles per image (35 anchor rows)
+    # thin input, 32 .. 128 output channels on large images: thin-input forward kernel with 64-column tiles
+    (2, 128, 128, 3, 64, 4, 2),    # pix2pix e1 geometry at half size: two output rows per workgroup
+    (1, 256, 256, 4, 64, 4, 2),    # pix2pix m1: one 128-pixel output row per workgroup
+    (1, 130, 250, 1, 128, 5, 2),   # two column tiles, ragged rows (125 pixels), one input channel
+    (2, 64, 128, 2, 40, 3, 1),     # stride 1, N = 40 inside one tile, K = 18 padded to 32
     # one output channel: the wave-per-pixel forward kernel (M >= 1024)
     (16, 16, 16, 64, 1, 4, 2),     # pix2pix m5 geometry at 64 channels
     (5, 15, 17, 24, 1, 3, 1),      # stride 1, odd sizes, C / 8 = 3 chunks per tap
