@@ -391,28 +391,51 @@ __global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, cons
   }
 }
 
-template <typename T, int VW>
+// DB: also the column sums of the stored du (the bias gradient of the conv in front of the batch norm: analytically zero,
+// numerically the same rounding residue a separate pass over du would find) as per-workgroup partials [blk][2][C] plane 0
+template <typename T, int VW, bool DB>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const ColGeom g, const T* __restrict__ dh, int dhcs, const T* __restrict__ pre,
                                                           const float* __restrict__ beta, const float* __restrict__ stats,
-                                                          const float* __restrict__ sums, int act, float leak, T* __restrict__ du) {
+                                                          const float* __restrict__ sums, int act, float leak, T* __restrict__ du,
+                                                          float* __restrict__ db_partial) {
+  __shared__ float sh[DB ? VW : 1][DB ? 256 : 1];
   const int CL = g.CL, RL = 256 / CL, C = g.C;
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int c = (blockIdx.y * CL + tx) * VW;
-  if (c >= C) return;
-  float rstd[VW], b[VW], m0[VW], m1[VW];
+  const bool okc = c < C;
+  if (!DB && !okc) return;
+  float rstd[VW], b[VW], m0[VW], m1[VW], acc[VW];
 #pragma unroll
-  for (int e = 0; e < VW; ++e) { rstd[e] = stats[C + c + e]; b[e] = beta[c + e]; m0[e] = sums[c + e]; m1[e] = sums[C + c + e]; }
-  for (int r = blockIdx.x * RL + ty; r < g.rows; r += gridDim.x * RL) {
-    const size_t i = (size_t)r * g.cs + c;
-    float d[VW], p[VW], o[VW];
-    load_vw<T, VW>(dh + (size_t)r * dhcs + c, d);
-    load_vw<T, VW>(pre + i, p);
+  for (int e = 0; e < VW; ++e) {
+    rstd[e] = okc ? stats[C + c + e] : 0.f; b[e] = okc ? beta[c + e] : 0.f; m0[e] = okc ? sums[c + e] : 0.f; m1[e] = okc ? sums[C + c + e] : 0.f;
+    acc[e] = 0.f;
+  }
+  if (okc)
+    for (int r = blockIdx.x * RL + ty; r < g.rows; r += gridDim.x * RL) {
+      const size_t i = (size_t)r * g.cs + c;
+      float d[VW], p[VW], o[VW];
+      load_vw<T, VW>(dh + (size_t)r * dhcs + c, d);
+      load_vw<T, VW>(pre + i, p);
 #pragma unroll
-    for (int e = 0; e < VW; ++e) {
-      const float f = act_deriv_from_pre(p[e], act, leak);
-      o[e] = rstd[e] * (d[e] * f - m0[e] - (p[e] - b[e]) * m1[e]);
+      for (int e = 0; e < VW; ++e) {
+        const float f = act_deriv_from_pre(p[e], act, leak);
+        o[e] = rstd[e] * (d[e] * f - m0[e] - (p[e] - b[e]) * m1[e]);
+        if (DB) acc[e] += to_f32<T>(from_f32<T>(o[e]));          // the value a pass over the stored tensor would read
+      }
+      store_vw<T, VW>(du + i, o);
     }
-    store_vw<T, VW>(du + i, o);
+  if constexpr (DB) {
+#pragma unroll
+    for (int e = 0; e < VW; ++e) sh[e][threadIdx.x] = acc[e];
+    __syncthreads();
+    if (ty == 0 && okc) {
+#pragma unroll
+      for (int e = 0; e < VW; ++e) {
+        float t = 0.f;
+        for (int k = 0; k < RL; ++k) t += sh[e][k * CL + tx];
+        db_partial[((size_t)blockIdx.x * 2 + 0) * C + c + e] = t;
+      }
+    }
   }
 }
 
@@ -502,7 +525,7 @@ extern "C" int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int 
 
 extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre, int rows, int c, int cs, const float* beta,
                           const float* stats, int act, float leak, void* du, float* dbeta, float beta_acc,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          float* dbias, float dbias_acc, void* workspace, size_t workspace_bytes, void* stream) {
   TDG_CHECK_ARG(dh && pre && beta && stats && du && dbeta && workspace, "tdg_bn_bwd: null pointer");
   TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c && dh_cs >= c, "tdg_bn_bwd: bad shape");
   if (workspace_bytes < tdg_bn_workspace_bytes(rows, c)) { tdg_set_error("tdg_bn_bwd: workspace too small"); return TDG_EWORKSPACE; }
@@ -511,22 +534,36 @@ extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre,
   g.xcs = dh_cs;
   ColArgs a; memset(&a, 0, sizeof(a));
   a.x = dh; a.y = pre; a.beta = beta; a.act = act; a.leak = leak; a.partial = static_cast<float*>(workspace);
-  float* sums = a.partial + (size_t)g.nblk * 2 * c;
+  float* sums = a.partial + (size_t)1024 * 2 * c;              // behind the partial planes (which the apply pass reuses)
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows; f.out0 = dbeta; f.out1 = sums; f.beta_acc = beta_acc;
   ColGeom ga = col_geom(rows, c, cs, dh, (const void*)((uintptr_t)pre | (uintptr_t)du), tdg_dtype_size(dtype), dh_cs % 4 == 0);
   ga.xcs = dh_cs;
-  const dim3 agrid(apply_row_blocks(ga), ga.ncol);
+  int arows = apply_row_blocks(ga);
+  if (dbias && arows > 1024) arows = 1024;                     // its column partials live in the 1024-block partial planes
+  const dim3 agrid(arows, ga.ncol);
+  FinArgs fb; memset(&fb, 0, sizeof(fb));
+  fb.partial = a.partial; fb.nblk = arows; fb.C = c; fb.rows = rows; fb.out0 = dbias; fb.beta_acc = dbias_acc;
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
     if (rc) return rc;
     hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
-    if (ga.vw == 4)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
-                         static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
-    else
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
-                         static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du));
+    if (dbias) {
+      if (ga.vw == 4)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, true>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
+                           static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du), a.partial);
+      else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
+                           static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du), a.partial);
+      hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, fb);
+    } else {
+      if (ga.vw == 4)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, false>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
+                           static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du), nullptr);
+      else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, false>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
+                           static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du), nullptr);
+    }
   })
   TDG_HIP_LAUNCH_CHECK("bn_bwd");
   return TDG_OK;

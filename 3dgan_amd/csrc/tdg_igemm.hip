@@ -2746,7 +2746,8 @@ bool plan_bwd_col2im(const TdgConvDesc* d, Col2imPlan* f) {
   if (!enabled || d->dtype != TDG_BF16 || d->stride != 2) return false;
   if (d->kh < 2 || d->kw < 2 || d->kh > 6 || d->kw > 6) return false;
   const int ncol = d->kh * d->kw * d->c;
-  if (ncol > 64) return false;
+  static const int maxcol = getenv("TDG_C2I_MAXCOL") ? atoi(getenv("TDG_C2I_MAXCOL")) : 64;   // diagnostics (<= 80)
+  if (ncol > maxcol || ncol > 80) return false;
   const int ke = eff_channels(d->k, d->ks, 8);
   if (!ke) return false;
   BwdClassPlan cls[IG_MAX_CLASSES];
@@ -2869,10 +2870,10 @@ bool plan_fwd_thin(const TdgConvDesc* d, ThinPlan* t) {
   static const int enabled = getenv("TDG_THIN") ? atoi(getenv("TDG_THIN")) : 1;   // diagnostics: 0 = implicit-GEMM kernels, 2 = only the 208-column form
   if (!enabled || d->dtype != TDG_BF16 || d->c > 4 || d->cs < 4 || (d->cs & 3) || (d->k & 7) || (d->ks & 7)) return false;
   if (d->ow > TH_PIX) return false;
-  // 208-column tiles for wide outputs; 64-column tiles for 32 .. 128 output channels on large images (narrow outputs on small
-  // images stay with the implicit-GEMM kernels: their launches are too small for the difference to show)
+  // 208-column tiles for wide outputs; 64-column tiles for 32 .. 128 output channels when the descriptor's batch has >= 64k
+  // output pixels (smaller launches stay with the implicit-GEMM kernels: too short for the difference to show)
   if (d->k >= 160) t->NC = 208;
-  else if (enabled != 2 && d->k >= 32 && d->k <= 128 && d->oh * d->ow >= 4096) t->NC = 64;
+  else if (enabled != 2 && d->k >= 32 && d->k <= 128 && (long long)d->n * d->oh * d->ow >= 65536) t->NC = 64;
   else return false;
   const int tile_rows = t->NC == 208 ? 224 : 64;
   t->Kp = (int)tdg_round_up((long long)d->kh * d->kw * d->c, 32);
@@ -3314,7 +3315,8 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
       case 1: hipLaunchKernelGGL(bwd_col2im_kernel<1>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
       case 2: hipLaunchKernelGGL(bwd_col2im_kernel<2>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
       case 3: hipLaunchKernelGGL(bwd_col2im_kernel<3>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
-      default: hipLaunchKernelGGL(bwd_col2im_kernel<4>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+      case 4: hipLaunchKernelGGL(bwd_col2im_kernel<4>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
+      default: hipLaunchKernelGGL(bwd_col2im_kernel<5>, grid, dim3(256), cp.lds, (hipStream_t)stream, f); break;
     }
     tdg_timing_stop((hipStream_t)stream);
     TDG_HIP_LAUNCH_CHECK("bwd_col2im");

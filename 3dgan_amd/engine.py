@@ -506,9 +506,14 @@ class SeqNet:
                     if getattr(L, 'dbeta_sink', None) is None:
                         L.dbeta_sink = torch.zeros(L.spec.out_size, dtype=torch.float32, device=self.device)
                     dbeta = L.dbeta_sink
+                # the pass that writes delta also sums its columns: the conv's bias gradient, when it covers the same rows
+                db_here = want_params and (q0, qn) == (r0, rn)
                 K.bn_bwd(self.ws, L.gout, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.bn_stats[bn_pass],
                          L.act.code, L.delta, dbeta, rows=rn * hw, leak=L.act.leak, beta_acc=0.0,
-                         dh_ptr=L.gout.ptr(r0), pre_ptr=L.pre.ptr(r0), du_ptr=L.delta.ptr(r0))
+                         dh_ptr=L.gout.ptr(r0), pre_ptr=L.pre.ptr(r0), du_ptr=L.delta.ptr(r0),
+                         dbias=g(L.bname) if db_here else None, dbias_acc=beta)
+                if db_here:
+                    have_db = (L, None)
             elif L.act.code in (K.ACT_TANH, K.ACT_SIGMOID):
                 _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,
                           L.act.leak, L.delta.ptr(r0), K.stream())
@@ -516,7 +521,9 @@ class SeqNet:
                 _lib.call('tdg_act_bwd', self.dtype, L.gout.ptr(r0), L.h.ptr(r0), rn * L.h.image_elems, L.act.code,
                           L.act.leak, L.delta.ptr(r0), K.stream())
             if want_params and qn > 0:
-                if have_db is not None and have_db[0] is L and K.nblk(have_db[1]):
+                if have_db is not None and have_db[0] is L and have_db[1] is None:
+                    pass                                   # taken by bn_bwd above
+                elif have_db is not None and have_db[0] is L and K.nblk(have_db[1]):
                     K.bias_grad_from_partials(have_db[1], L.spec.out_size, g(L.bname), beta)
                 else:
                     K.bias_grad(self.ws, L.delta, L.spec.out_size, g(L.bname), rows=qn * hw, beta=beta, dy_ptr=L.delta.ptr(q0))

@@ -301,13 +301,15 @@ def bn_fwd(ws, u, c, beta, act, pre, h, stats, rows=None, leak=0.2, eps=1e-3, u_
 
 
 def bn_bwd(ws, dh, pre, c, beta, stats, act, du, dbeta, rows=None, leak=0.2, beta_acc=0.0,
-           dh_ptr=None, pre_ptr=None, du_ptr=None):
+           dh_ptr=None, pre_ptr=None, du_ptr=None, dbias=None, dbias_acc=0.0):
+    """dbias: also the bias gradient of the conv in front of the batch norm (column sums of du), from the same pass."""
     rows = dh.rows if rows is None else rows
     lib = _lib.load()
     need = lib.tdg_bn_workspace_bytes(rows, c)
     w = ws.ensure(need)
     _lib.call('tdg_bn_bwd', dh.dtype, dh_ptr or dh.ptr(), dh.cs, pre_ptr or pre.ptr(), rows, c, pre.cs, ptr(beta), ptr(stats),
-              act, leak, du_ptr or du.ptr(), ptr(dbeta), beta_acc, ptr(w), w.numel(), stream())
+              act, leak, du_ptr or du.ptr(), ptr(dbeta), beta_acc, ptr(dbias) if dbias is not None else None, dbias_acc,
+              ptr(w), w.numel(), stream())
 
 
 def bias_grad(ws, dy, c, db, rows=None, beta=0.0, dy_ptr=None):

@@ -496,8 +496,7 @@ class UNet:
             if self.d_keep[i] > 0:
                 self._dropout(self.d_g[i], i)                                     # d(dropout)/dh = the same mask / keep
             K.bn_bwd(self.ws, self.d_g[i], self.d_pre[i], spec.out_size, st[self.d_bn_name[i]], self.d_stats[i], spec.act.code,
-                     self.d_delta[i], g(self.d_bn_name[i]), leak=spec.act.leak)
-            K.bias_grad(self.ws, self.d_delta[i], spec.out_size, g(self.dnet.var_name(spec, 'bias')))
+                     self.d_delta[i], g(self.d_bn_name[i]), leak=spec.act.leak, dbias=g(self.dnet.var_name(spec, 'bias')))
             src = self._d_in(i)
             conv.bwd_filter(self.d_delta[i].ptr(), src.ptr(), g(self.dnet.var_name(spec, 'weights')), B, 0.0)
             if i > 1:
@@ -508,9 +507,10 @@ class UNet:
             spec, conv = E[k - 1], self.e_conv[k]
             if self.enc_bn[k - 1]:
                 K.bn_bwd(self.ws, self.e_g[k], self.e_pre[k], spec.out_size, st[self.e_bn_name[k]], self.e_stats[k], spec.act.code,
-                         self.e_delta[k], g(self.e_bn_name[k]), leak=spec.act.leak)
+                         self.e_delta[k], g(self.e_bn_name[k]), leak=spec.act.leak, dbias=g(self.enet.var_name(spec, 'bias')))
             delta = self.e_delta[k]
-            K.bias_grad(self.ws, delta, spec.out_size, g(self.enet.var_name(spec, 'bias')))
+            if not self.enc_bn[k - 1]:
+                K.bias_grad(self.ws, delta, spec.out_size, g(self.enet.var_name(spec, 'bias')))
             src = self.x_in if k == 1 else self.e_h[k - 1]
             conv.bwd_filter(src.ptr(), delta.ptr(), g(self.enet.var_name(spec, 'weights')), B, 0.0)
             if k > 1:

@@ -202,9 +202,11 @@ int tdg_add_act(int dtype, const void* a, const void* b, size_t n, int act, floa
 int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
                              float leak, void* pre, void* h, int h_cs, float* stats, const float* partial, int nblk,
                              const float* pivot_bias, void* stream);
+/* dbias (optional): += / = the column sums of the stored du, i.e. the bias gradient of the conv in front of the batch
+ * norm (BiasAddGrad of ops/layers.py:102 under :103), taken from the pass that writes du instead of a pass of its own. */
 int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre, int rows, int c, int cs,
                const float* beta, const float* stats, int act, float leak, void* du, float* dbeta,
-               float beta_acc, void* workspace, size_t workspace_bytes, void* stream);
+               float beta_acc, float* dbias, float dbias_acc, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- elementwise ------------------------------------------------------------------------ */
 /* y = act(x + bias[c]) over rows x c (tf.nn.bias_add + activation) */

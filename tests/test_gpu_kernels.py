@@ -58,6 +58,7 @@ CONV_CASES = [
     (1, 256, 256, 4, 64, 4, 2),    # pix2pix m1: one 128-pixel output row per workgroup
     (1, 130, 250, 1, 128, 5, 2),   # two column tiles, ragged rows (125 pixels), one input channel
     (2, 64, 128, 2, 40, 3, 1),     # stride 1, N = 40 inside one tile, K = 18 padded to 32
+    (66, 64, 64, 3, 64, 5, 2),     # VAE c1 (32 x 32 outputs, four output rows per workgroup) at a batch past the 64k-pixel threshold
     # one output channel: the wave-per-pixel forward kernel (M >= 1024)
     (16, 16, 16, 64, 1, 4, 2),     # pix2pix m5 geometry at 64 channels
     (5, 15, 17, 24, 1, 3, 1),      # stride 1, odd sizes, C / 8 = 3 chunks per tap
@@ -266,6 +267,17 @@ def test_batch_norm(shape, dtype):
     ref_du = rstd * (dpre - dpre.mean(0) - xhat * (dpre * xhat).mean(0))
     assert relerr(du.get().reshape(rows, c), ref_du) < 5 * TOL[dtype]
     assert relerr(dbeta.cpu().numpy(), dpre.sum(0)) < 5 * TOL[dtype]
+    # the same pass with the bias gradient of the conv in front (column sums of the stored du, accumulated onto 0.25):
+    # identical du, and the sums a separate pass over du finds (analytically zero: compared on the scale of sum |du|)
+    du2, dbeta2 = ua.like(), torch.zeros(c, device=dev)
+    dbias = torch.full((c,), 0.25, device=dev)
+    K.bn_bwd(ws, dha, pre, c, bd, stats, K.ACT_RELU, du2, dbeta2, dbias=dbias, dbias_acc=1.0)
+    got = du2.get().reshape(rows, c)
+    assert np.array_equal(got, du.get().reshape(rows, c))
+    assert np.array_equal(dbeta2.cpu().numpy(), dbeta.cpu().numpy())
+    want = got.astype(np.float64).sum(0)
+    scale = np.abs(got).sum(0).max() + 1e-30
+    assert np.abs(dbias.cpu().numpy() - 0.25 - want).max() / scale < 1e-6
 
 
 @pytest.mark.parametrize('dtype', [0, 1])
