@@ -14,14 +14,16 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_two_replicas_match_one(tmp_path):
+@pytest.mark.parametrize('model,port', [('iwgan', 29533), ('wgan', 29534), ('vae', 29535)])
+def test_two_replicas_match_one(tmp_path, model, port):
+    """iwgan: the headline schedule; wgan: config 3's model (rmsprop, one exchange per step); vae: config 5's model."""
     worker = os.path.join(ROOT, 'tests', '_dist_worker.py')
     env = dict(os.environ, TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
     env1 = {k: v for k, v in env.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
-    subprocess.run([sys.executable, worker, one], check=True, env=env1, timeout=600)
+    subprocess.run([sys.executable, worker, one, model], check=True, env=env1, timeout=600)
     subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
-                    '127.0.0.1', '--master-port', '29533', worker, two], check=True, env=env1, timeout=600)
+                    '127.0.0.1', '--master-port', str(port), worker, two, model], check=True, env=env1, timeout=600)
     a, b = np.load(one), np.load(two)
     assert set(a.files) == set(b.files)
     for k in a.files:
