@@ -2470,9 +2470,10 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   for (int c = 0; c < a.nclasses; ++c) smax = a.cls[c].nsteps > smax ? a.cls[c].nsteps : smax;
   const long long wgs = (long long)a.ntiles_n * a.ntiles_m_max * a.nclasses;
   const int ks_force = getenv("TDG_KSPLIT") ? atoi(getenv("TDG_KSPLIT")) : 0;                  // diagnostics: 1 = never, n = n splits
-  if (!WS && t_splitk && t_splitk->splitk_ws && wgs <= 96 && smax >= 16 && n_begin == 0 && a.ntiles_n * BN >= a.N && ks_force != 1) {
+  if (!WS && t_splitk && t_splitk->splitk_ws && wgs <= 128 && smax >= 16 && n_begin == 0 && a.ntiles_n * BN >= a.N && ks_force != 1) {
     int want = (int)(256 / wgs);
     if (want > smax / 4) want = smax / 4;                    // >= 4 steps per split
+    if (want > 8) want = 8;                                  // measured (64 images, 512 -> 512, 4x4 s2): 2x2 / 4x4 inputs 0.019 / 0.020 ms at 8 splits, 0.026 / 0.032 at 32
     if (ks_force > 1) want = ks_force;
     const int per = tdg_ceil_div(smax, want);
     const int nsplit = tdg_ceil_div(smax, per);
