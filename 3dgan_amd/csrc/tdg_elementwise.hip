@@ -901,6 +901,12 @@ extern "C" int tdg_affine_cast(int dtype, const float* in, size_t n, float scale
 template <typename T>
 __global__ void __launch_bounds__(256) affine_cast_rows_kernel(const float* __restrict__ in, size_t n, int c, int cs, float scale,
                                                               float shift, T* __restrict__ out) {
+  if (c <= 16) {              // images: one pixel per thread and trip, no 64-bit division per element
+    const size_t rows = n / (size_t)c;
+    for (size_t r = blockIdx.x * (size_t)256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256)
+      for (int ch = 0; ch < c; ++ch) out[r * cs + ch] = from_f32<T>(scale * (in[r * c + ch] + shift));
+    return;
+  }
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     const size_t r = i / c;
     const int ch = (int)(i - r * c);
@@ -1228,13 +1234,17 @@ __global__ void __launch_bounds__(256) vae_bce_kernel(const float* __restrict__ 
                                                      T* __restrict__ seed, float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t r = i / c;
-    const int ch = (int)(i - r * c);
-    const size_t j = r * cs + ch;
-    const float xv = x[i], dv = to_f32<T>(d[j]);
-    s -= xv * logf(1e-8f + dv) + (1.f - xv) * logf(1e-8f + (1.f - dv));
-    seed[j] = from_f32<T>(-(xv / (1e-8f + dv) - (1.f - xv) / (1e-8f + (1.f - dv))));
+  // one pixel row per thread and trip (an element-indexed loop paid a 64-bit division per element: 69 us for 6.3 M elements)
+  const size_t rows = n / (size_t)c;
+  for (size_t r = blockIdx.x * (size_t)256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+    const float* xr = x + r * c;
+    const T* dr = d + r * cs;
+    T* sr = seed + r * cs;
+    for (int ch = 0; ch < c; ++ch) {
+      const float xv = xr[ch], dv = to_f32<T>(dr[ch]);
+      s -= xv * logf(1e-8f + dv) + (1.f - xv) * logf(1e-8f + (1.f - dv));
+      sr[ch] = from_f32<T>(-(xv / (1e-8f + dv) - (1.f - xv) / (1e-8f + (1.f - dv))));
+    }
   }
   s = block_sum256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -1259,13 +1269,16 @@ __global__ void __launch_bounds__(256) l1_loss_kernel(const float* __restrict__ 
                                                      float* __restrict__ partial) {
   __shared__ float sh[4];
   float s = 0.f;
-  for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const size_t r = i / c;
-    const int ch = (int)(i - r * c);
-    const size_t j = r * cs + ch;
-    const float u = scale * (x[i] + shift) - to_f32<T>(d[j]);           // x - d on the rescaled input
-    s += fabsf(u);
-    seed[j] = from_f32<T>(u > 0.f ? -inv_n : (u < 0.f ? inv_n : 0.f));   // AbsGrad: sign(u), sign(0) = 0; d u / d d = -1
+  const size_t rows = n / (size_t)c;
+  for (size_t r = blockIdx.x * (size_t)256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+    const float* xr = x + r * c;
+    const T* dr = d + r * cs;
+    T* sr = seed + r * cs;
+    for (int ch = 0; ch < c; ++ch) {
+      const float u = scale * (xr[ch] + shift) - to_f32<T>(dr[ch]);      // x - d on the rescaled input
+      s += fabsf(u);
+      sr[ch] = from_f32<T>(u > 0.f ? -inv_n : (u < 0.f ? inv_n : 0.f));   // AbsGrad: sign(u), sign(0) = 0; d u / d d = -1
+    }
   }
   s = block_sum256(s, sh);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
