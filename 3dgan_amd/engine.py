@@ -638,6 +638,7 @@ class Residual:
         self.names = {w: '%s/vars/%s%s/%s' % (net.name, spec.name, ab, w2) for ab in 'AB' for w2 in ('weights', 'bias')
                       for w in ['%s%s' % (ab, w2[0])]}              # Aw, Ab, Bw, Bb
         self.shapes = {'Aw': (spec.k, spec.k, spec.in_size, oc), 'Ab': (oc,), 'Bw': (spec.k, spec.k, oc, oc), 'Bb': (oc,)}
+        self._sink = torch.zeros(oc, dtype=torch.float32, device=dev)     # beta gradients of passes that do not want parameters
         if spec.use_bn:
             self.statsA = [torch.zeros(2 * oc, dtype=torch.float32, device=dev) for _ in range(n_bn_passes)]
             self.statsB = [torch.zeros(2 * oc, dtype=torch.float32, device=dev) for _ in range(n_bn_passes)]
@@ -683,7 +684,7 @@ class Residual:
         act, oc, dt = L.act, sp.out_size, self.seq.dtype
         hw = self.S.h * self.S.w
         rows, nel = rn * hw, rn * self.S.image_elems
-        sink = self.__dict__.setdefault('_sink', torch.zeros(oc, dtype=torch.float32, device=self.seq.device))
+        sink = self._sink
         # dZ = dOut * act'(out)
         _lib.call('tdg_act_bwd', dt, L.gout.ptr(r0), L.h.ptr(r0), nel, act.code, act.leak, self.dZ.ptr(r0), K.stream())
         if sp.use_bn:

@@ -45,6 +45,16 @@ def main():
         for nm, d in (('prologue + K loop', ph[:, :, 1] - ph[:, :, 0]), ('epilogue -> LDS', ph[:, :, 2] - ph[:, :, 1]),
                       ('LDS -> global', ph[:, :, 3] - ph[:, :, 2])):
             print('%-18s %5.1f %% of the workgroup lifetime (mean %.0f ticks)' % (nm, 100 * (d / life).mean(), d.mean()))
+    if ph.shape[0] and ph.shape[0] == st.shape[0]:
+        # prologue of each workgroup = (kernel entry -> end of the K loop) minus the loop's own stamped cycles (wave 0), by
+        # start order: the first 256 workgroups are the launch's first round (every CU in its prologue at once)
+        pro = (ph[:, 0, 1] - ph[:, 0, 0]) - (st[:, 0, 0] + st[:, 0, 1] + st[:, 0, 2])
+        order = torch.argsort(ph[:, 0, 0])
+        pro = pro[order]
+        q = lambda t: ' '.join('%.0f' % v for v in torch.quantile(t, torch.tensor([0.05, 0.5, 0.95], dtype=t.dtype)).tolist())
+        print('prologue cycles (5 / 50 / 95 %%): first 256 workgroups %s | the rest %s' % (q(pro[:256]), q(pro[256:]) if pro.numel() > 256 else '-'))
+        t0 = ph[order, 0, 0]
+        print('start spread of the first 256: %.0f cycles; of all: %.0f' % ((t0[255] - t0[0]).item() if t0.numel() > 255 else -1, (t0[-1] - t0[0]).item()))
     per_wave = (st[:, :, :3] / steps[:, :, None]).mean(0)
     for wv in range(8):
         print('wave %d: issue %.1f mma %.1f barrier %.1f' % (wv, *per_wave[wv].tolist()))
