@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, cons
     load_vw<T, VW>(u + i, v);
 #pragma unroll
     for (int e = 0; e < VW; ++e) { p[e] = (v[e] - mean[e]) * rstd[e] + b[e]; a[e] = apply_act(p[e], act, leak); }
-    store_vw<T, VW>(pre + i, p);
+    if (pre) store_vw<T, VW>(pre + i, p);                       // (null: a forward pass no backward pass will follow)
     store_vw<T, VW>(h + (size_t)r * hcs + c, a);
   }
 }
@@ -503,7 +503,7 @@ extern "C" int tdg_col_finalize_sum(const float* partial, int nblk, int c, float
 extern "C" int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
                                         float leak, void* pre, void* h, int h_cs, float* stats, const float* partial, int nblk,
                                         const float* pivot_bias, void* stream) {
-  TDG_CHECK_ARG(u && beta && pre && h && stats && partial && nblk > 0, "tdg_bn_fwd_from_partials: null pointer");
+  TDG_CHECK_ARG(u && beta && h && stats && partial && nblk > 0, "tdg_bn_fwd_from_partials: null pointer");
   TDG_CHECK_ARG(rows > 0 && c > 0 && cs >= c && h_cs >= c, "tdg_bn_fwd_from_partials: bad shape rows=%d c=%d cs=%d h_cs=%d", rows, c, cs, h_cs);
   hipStream_t s = (hipStream_t)stream;
   FinArgs f; memset(&f, 0, sizeof(f));

@@ -404,8 +404,9 @@ class SeqNet:
             K.pack_all(self._pack_jobs)
 
     # -- forward -----------------------------------------------------------------------------------
-    def forward(self, img0, n, bn_pass=0):
-        """Layers on images [img0, img0+n).  Returns the last layer's output (Act or f32 scores)."""
+    def forward(self, img0, n, bn_pass=0, keep_pre=True):
+        """Layers on images [img0, img0+n).  Returns the last layer's output (Act or f32 scores).  keep_pre=False: no backward
+        pass will follow, so batch-norm layers skip writing their normalised pre-activation (only its activation)."""
         for L in self.layers:
             r0, rn = img0 * L.rpi, n * L.rpi
             if L.rowdot:
@@ -437,7 +438,8 @@ class SeqNet:
             elif L.spec.use_bn:
                 rows = rn * L.h.h * L.h.w
                 if K.nblk(epi):
-                    K.bn_fwd_from_partials(epi, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code, L.pre, L.h,
+                    K.bn_fwd_from_partials(epi, L.pre, L.spec.out_size, self.store[L.bn_names[bn_pass]], L.act.code,
+                                           L.pre if keep_pre else None, L.h,
                                            L.bn_stats[bn_pass], bias, rows=rows, leak=L.act.leak,
                                            u_ptr=L.pre.ptr(r0), pre_ptr=L.pre.ptr(r0), h_ptr=L.h.ptr(r0))
                 else:                                  # (f32 tiles, thin layers: the separate statistics pass)

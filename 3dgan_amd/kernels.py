@@ -131,9 +131,11 @@ def bias_grad_from_partials(e, c, db, beta=0.0):
 
 
 def bn_fwd_from_partials(e, u, c, beta, act, pre, h, stats, bias, rows=None, leak=0.2, eps=1e-3, u_ptr=None, pre_ptr=None, h_ptr=None):
+    """pre=None: only h is written (a forward pass that no backward pass will follow)."""
     rows = u.rows if rows is None else rows
     _lib.call('tdg_bn_fwd_from_partials', u.dtype, u_ptr or u.ptr(), rows, c, u.cs, ptr(beta), eps, act, leak,
-              pre_ptr or pre.ptr(), h_ptr or h.ptr(), h.cs, ptr(stats), C.c_void_p(e.col_partial), nblk(e), ptr(bias), stream())
+              (pre_ptr or pre.ptr()) if pre is not None else None, h_ptr or h.ptr(), h.cs, ptr(stats), C.c_void_p(e.col_partial),
+              nblk(e), ptr(bias), stream())
 
 
 class GemmTimer:

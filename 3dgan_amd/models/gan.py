@@ -16,6 +16,8 @@ second-order term is the hand-derived tangent pass of engine.SeqNet.tangent_back
 scalars stay on the device until the end of the step; gradients live in one flat bucket per net
 (one RCCL all-reduce + one fused optimizer launch).
 """
+import os
+
 import torch
 
 from .. import _lib
@@ -169,9 +171,9 @@ class GanReplica(engine.GraphRunner):
         _lib.call('tdg_affine_cast_rows', self.sess.dtype, K.ptr(self.x_stage), self.B * h * w, c, self.D.x.cs, 2.0, -0.5,
                   self.D.x.ptr(0), K.stream())
 
-    def _generate(self):
+    def _generate(self, backward_follows=True):
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246
-        self.G.forward(0, self.B)                                      # g lands in D.x slot 1
+        self.G.forward(0, self.B, keep_pre=backward_follows)           # g lands in D.x slot 1
 
     def samples(self, n):
         """(inputs, fake) as float32 NHWC in [-1, 1]: the first n images of the staged real batch and of a fresh
@@ -179,7 +181,7 @@ class GanReplica(engine.GraphRunner):
         h, w, c = self.args.image_shape
         n = min(n, self.B)
         self._rescale_real()
-        self._generate()
+        self._generate(backward_follows=False)
         view = self.D.x.buf[:2 * self.B * h * w * self.D.x.cs].view(2, self.B, h, w, self.D.x.cs)
         both = view[:, :n, :, :, :c].float().cpu().numpy()
         return both[0], both[1]
@@ -292,7 +294,7 @@ class GanReplica(engine.GraphRunner):
         B, R = self.B, self.B * self.rows_per_image
         self._clip_critic()
         self._rescale_real()
-        self._generate()
+        self._generate(backward_follows=False)                         # the critic step does not back-propagate into G
         if self.iwgan:
             self._interpolate()
         scores = self._d_forward(0, self.nslots)

@@ -198,7 +198,8 @@ int tdg_instance_norm_bwd(int dtype, const void* dh, int dh_cs, const void* u, i
 /* out = act(a + b), flat, one layout: the shortcut sum of `residual` (hem/ops/layers.py:297-304); TDG_ACT_NONE = add */
 int tdg_add_act(int dtype, const void* a, const void* b, size_t n, int act, float leak, void* out, void* stream);
 /* tdg_bn_fwd with the batch statistics taken from TDG_COL_BN partials of the producing conv (pivot = that conv's
- * bias, may be NULL) instead of a pass over u: stats, then pre = (u - mean) * rstd + beta and h = act(pre). */
+ * bias, may be NULL) instead of a pass over u: stats, then pre = (u - mean) * rstd + beta and h = act(pre).
+ * pre may be NULL when no backward pass will follow this forward pass (the generator pass of a critic step): only h is written. */
 int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps, int act,
                              float leak, void* pre, void* h, int h_cs, float* stats, const float* partial, int nblk,
                              const float* pivot_bias, void* stream);
