@@ -246,7 +246,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
     def _d_grads(self):
         B = self.B
         self._rescale()
-        self.U.forward()
+        self.U.forward(backward_follows=False)
         self._d_forward(0, 2)
         self._xent(1)
         if self.args.batch_norm_disc:
@@ -287,7 +287,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
 
     def _report_body(self):
         self._rescale()
-        self.U.forward()
+        self.U.forward(backward_follows=False)
         self._d_forward(0, 2)
         self._xent(0)
         self._l1(False)
@@ -449,9 +449,12 @@ class UNet:
             _lib.call('tdg_affine_cast_rows', self.dtype, K.ptr(u), self.B * a.h * a.w, a.c, a.cs, 2.0, -0.5, a.ptr(0), K.stream())
 
     # ---- forward: G(x) into g_out ---------------------------------------------------------------------------------
-    def forward(self):
+    def forward(self, backward_follows=True):
+        """backward_follows=False (the critic step's and the loss fetch's generator pass): batch-norm layers write only their
+        activation, not the normalised pre-activation the backward pass would read."""
         B, st = self.B, self.store
         E, Dc = self.enet.layers, self.dnet.layers
+        self._keep_pre = backward_follows
         self.draw_noise()
         for k in range(1, 9):
             spec, conv = E[k - 1], self.e_conv[k]
@@ -478,7 +481,8 @@ class UNet:
         """Batch norm + activation of a layer whose GEMM has just stored `pre`: statistics from the epilogue's column
         partials when the launch provided them, else by the separate pass."""
         if K.nblk(epi):
-            K.bn_fwd_from_partials(epi, pre, spec.out_size, beta, spec.act.code, pre, h, stats, bias, leak=spec.act.leak)
+            K.bn_fwd_from_partials(epi, pre, spec.out_size, beta, spec.act.code, pre if self._keep_pre else None, h, stats, bias,
+                                   leak=spec.act.leak)
         else:
             K.bn_fwd(self.ws, pre, spec.out_size, beta, spec.act.code, pre, h, stats, leak=spec.act.leak)
 
