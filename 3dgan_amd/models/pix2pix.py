@@ -271,8 +271,8 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         B = self.B
         self._rescale()
         self.U.forward()
-        self._d_forward(0, 2)                  # both passes: with batch norm the statistics are per pass anyway
-        self._xent(2)
+        self._d_forward(1, 1)                  # only D(x, G(x)): sess.run(g_train_op) evaluates nothing of the real pass
+        self._xent(2)                          # (hem/models/pix2pix.py:153; the losses are fetched by report() on a third batch)
         if self.args.batch_norm_disc:
             self.D.backward(B, B, bn_pass=1, want_params=False, want_dx=True)
         else:
