@@ -913,6 +913,33 @@ __global__ void __launch_bounds__(256) affine_cast_rows_kernel(const float* __re
     out[r * cs + ch] = from_f32<T>(scale * (in[i] + shift));
   }
 }
+// pix2pix's critic input: out_ab[r] = scale * ([a[r] | b[r]] + shift), out_a0[r] = scale * ([a[r] | .] + shift) with zeros in b's
+// channels (the generator writes them later), ca + cb == 4 channels per pixel: one pass with 8 / 16-byte stores instead of three
+// tdg_affine_cast_rows passes with 2-byte ones
+template <typename T>
+__global__ void __launch_bounds__(256) affine_cast_pair_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b, int cb,
+                                                              size_t rows, float scale, float shift, T* __restrict__ out_ab,
+                                                              T* __restrict__ out_a0) {
+  for (size_t r = blockIdx.x * (size_t)256 + threadIdx.x; r < rows; r += (size_t)gridDim.x * 256) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < ca; ++ch) v[ch] = w[ch] = scale * (a[r * ca + ch] + shift);
+    for (int ch = 0; ch < cb; ++ch) v[ca + ch] = scale * (b[r * cb + ch] + shift);
+    store_vw<T, 4>(out_ab + r * 4, v);
+    store_vw<T, 4>(out_a0 + r * 4, w);
+  }
+}
+extern "C" int tdg_affine_cast_pair(int dtype, const float* a, int ca, const float* b, int cb, size_t rows, float scale, float shift,
+                                    void* out_ab, void* out_a0, void* stream) {
+  TDG_CHECK_ARG(a && b && out_ab && out_a0 && rows > 0 && ca > 0 && cb > 0 && ca + cb == 4, "tdg_affine_cast_pair: bad argument");
+  TDG_CHECK_ARG((((uintptr_t)out_ab | (uintptr_t)out_a0) & 15) == 0, "tdg_affine_cast_pair: outputs must be 16-byte aligned");
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(affine_cast_pair_kernel<T>, dim3(ew_blocks(rows)), dim3(256), 0, (hipStream_t)stream, a, ca, b, cb, rows, scale,
+                       shift, static_cast<T*>(out_ab), static_cast<T*>(out_a0));
+  })
+  TDG_HIP_LAUNCH_CHECK("affine_cast_pair");
+  return TDG_OK;
+}
+
 extern "C" int tdg_affine_cast_rows(int dtype, const float* in, int rows, int c, int cs, float scale, float shift, void* out,
                                     void* stream) {
   TDG_CHECK_ARG(in && out && rows > 0 && c > 0 && cs >= c, "tdg_affine_cast_rows: bad argument");

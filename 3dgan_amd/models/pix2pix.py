@@ -200,9 +200,13 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         """hem.rescale((0,1) -> (-1,1)) of both halves (hem/models/pix2pix.py:103-104) into D's input slots."""
         B, dt = self.B, self.sess.dtype
         rows, cs = B * 256 * 256, self.D.x.cs
-        for img0 in (0, B):
-            _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, cs, 2.0, -0.5, self.D.x.ptr(img0), K.stream())
-        _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.y_stage), rows, 1, cs, 2.0, -0.5, self.D.x.window(3, 1).ptr(0), K.stream())
+        if cs == 4:                                # [x | y] and [x | (G(x): written by the generator pass)] in one pass
+            _lib.call('tdg_affine_cast_pair', dt, K.ptr(self.x_stage), 3, K.ptr(self.y_stage), 1, rows, 2.0, -0.5, self.D.x.ptr(0),
+                      self.D.x.ptr(B), K.stream())
+        else:
+            for img0 in (0, B):
+                _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, cs, 2.0, -0.5, self.D.x.ptr(img0), K.stream())
+            _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.y_stage), rows, 1, cs, 2.0, -0.5, self.D.x.window(3, 1).ptr(0), K.stream())
         if self.U.xn is not None:                  # --noise input: the generator reads [x | noise] from its own buffer
             _lib.call('tdg_affine_cast_rows', dt, K.ptr(self.x_stage), rows, 3, self.U.xn.cs, 2.0, -0.5, self.U.xn.ptr(0), K.stream())
 

@@ -218,6 +218,11 @@ int tdg_act_bwd(int dtype, const void* dy, const void* post, size_t n, int act, 
                 void* stream);
 /* out = scale * (in + shift), f32 in -> dtype out   (models/gan.py:50: 2*(x-0.5)) */
 int tdg_affine_cast(int dtype, const float* in, size_t n, float scale, float shift, void* out, void* stream);
+/* Two 4-channel activations from two compact f32 row sets (ca + cb == 4): out_ab[r] = scale * ([a[r] | b[r]] + shift) and
+ * out_a0[r] = the same with zeros in b's channels -- pix2pix's critic inputs [x | y] and [x | G(x) to come]
+ * (hem/models/pix2pix.py:103-104 rescale + the concat of :236) in one pass. */
+int tdg_affine_cast_pair(int dtype, const float* a, int ca, const float* b, int cb, size_t rows, float scale, float shift,
+                         void* out_ab, void* out_a0, void* stream);
 /* out[r*cs + ch] = scale * (in[r*c + ch] + shift), ch < c: compact f32 rows -> channel-padded activation */
 int tdg_affine_cast_rows(int dtype, const float* in, int rows, int c, int cs, float scale, float shift, void* out,
                          void* stream);
