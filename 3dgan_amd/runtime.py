@@ -116,7 +116,7 @@ class Session:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t /= self.world_size
         else:
-            dist.broadcast(t, src=self.world_size - 1)
+            dist.broadcast(t, src=dist.get_world_size() - 1)      # the last rank of the group actually joined
         return t
 
     def assert_finite(self, store, what):

@@ -50,3 +50,24 @@ def test_bench_self_launches_its_ranks(tmp_path):
     for k in ('d_big_slice', 'd_rest', 'g_bucket'):
         assert c[k]['ms'] > 0 and c[k]['bytes'] > 0
     assert 'roofline' in out and 'cpu_baseline' not in out
+
+
+@pytest.mark.parametrize('model', ['iwgan', 'vae'])
+def test_rccl_runs_the_exchange_path(tmp_path, model):
+    """RCCL itself on the one-GPU box: a ONE-rank `nccl` process group (the only RCCL configuration one device allows) under a
+    replica that takes its N > 1 code path (split critic bodies, asynchronous slice all-reduce, 1/n in the optimizer, hipGraph
+    capture beside RCCL's watchdog thread).  With one rank every all-reduce is the identity, so the run must equal the same
+    run over a one-rank gloo group bit for bit."""
+    worker = os.path.join(ROOT, 'tests', '_dist_worker.py')
+    base = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    outs = {}
+    for i, backend in enumerate(('gloo', 'nccl')):
+        outs[backend] = str(tmp_path / (backend + '.npz'))
+        env = dict(base, TDG_DIST_BACKEND=backend, TDG_FAKE_WORLD='2', TDG_PORT=str(29551 + i), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        p = subprocess.run([sys.executable, worker, outs[backend], model], env=env, timeout=600, capture_output=True, text=True)
+        assert p.returncode == 0, (backend, p.stderr[-3000:])
+    a, b = np.load(outs['gloo']), np.load(outs['nccl'])
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.all(np.isfinite(a[k])), k
+        assert np.array_equal(a[k], b[k]), k
