@@ -3412,6 +3412,15 @@ static bool wgrad_use_dma(const TdgConvDesc* d) {
   return ce != 0 && (bn == 208 || (bn == 128 && d->k > 112)) && (long long)d->kh * d->kw * ce >= min_kk;
 }
 
+// column tile of the filter-gradient GEMM: pick_bn's, except that the LDS-DMA kernel takes 256-column tiles for N % 256 == 0
+// (pix2pix / VAE widths 256, 512, 1024: a third fewer operand bytes per MAC than 256 x 128)
+static int wgrad_bn(const TdgConvDesc* d) {
+  const int bn = pick_bn(d->k);
+  static const int wide = getenv("TDG_WG256") ? atoi(getenv("TDG_WG256")) : 1;     // diagnostics: 0 = 128-column tiles
+  if (wide && bn == 128 && wgrad_use_dma(d) && d->k % 256 == 0) return 256;
+  return bn;
+}
+
 static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   const int es = tdg_dtype_size(d->dtype), vec = 16 / es;
   const int mr = d->dtype == TDG_BF16 ? WgGeom<bf16_t>::MR : WgGeom<float>::MR;
@@ -3419,7 +3428,7 @@ static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   if (!ce) ce = d->c;
   const int M = n_images * d->oh * d->ow;
   const bool dma = wgrad_use_dma(d);
-  const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, dma ? 256 : 128) * tdg_ceil_div(d->k, pick_bn(d->k));
+  const int tiles = tdg_ceil_div((long long)d->kh * d->kw * ce, dma ? 256 : 128) * tdg_ceil_div(d->k, wgrad_bn(d));
   int want = tdg_ceil_div(768, tiles);                  // register-staged kernel: ~3 workgroups per CU
   if (dma) {
     // one workgroup per CU: the fewest splits (each costs an f32 slab written and re-read) whose last round of
@@ -3516,7 +3525,7 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
   a.Nlog = d->k;
   a.nsplit = wgrad_nsplit(d, n_images, &a.m_per_split);
   a.slab_stride = tdg_round_up((long long)a.ntaps * d->c * d->k, 4);
-  const int bn = pick_bn(d->k);
+  const int bn = wgrad_bn(d);
   const bool dma = wgrad_use_dma(d);
   a.ntiles_n = tdg_ceil_div(a.N, bn);
   a.ntiles_k = tdg_ceil_div(a.KK, dma ? 256 : 128);
@@ -3536,7 +3545,7 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
     return mode == 1 ? launch_wgrad_dma<B, 1>(a, (hipStream_t)stream)
                      : (mode == 2 ? launch_wgrad_dma<B, 2>(a, (hipStream_t)stream) : launch_wgrad_dma<B, 0>(a, (hipStream_t)stream));
   };
-  rc = dma ? (bn == 208 ? go(std::integral_constant<int, 208>{}) : go(std::integral_constant<int, 128>{}))
+  rc = dma ? (bn == 208 ? go(std::integral_constant<int, 208>{}) : bn == 256 ? go(std::integral_constant<int, 256>{}) : go(std::integral_constant<int, 128>{}))
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);
   if (rc) return rc;
