@@ -59,6 +59,10 @@ CONV_CASES = [
     (1, 130, 250, 1, 128, 5, 2),   # two column tiles, ragged rows (125 pixels), one input channel
     (2, 64, 128, 2, 40, 3, 1),     # stride 1, N = 40 inside one tile, K = 18 padded to 32
     (66, 64, 64, 3, 64, 5, 2),     # VAE c1 (32 x 32 outputs, four output rows per workgroup) at a batch past the 64k-pixel threshold
+    # 256-column filter-gradient tiles (N % 256 == 0) in each loader mode
+    (16, 8, 8, 64, 256, 5, 2),     # whole-image steps (4 x 4 outputs)
+    (2, 32, 32, 64, 512, 4, 2),    # rectangle steps (16 x 16 outputs), two column tiles
+    (2, 14, 18, 32, 256, 3, 1),    # generic loader: odd sizes
     # one output channel: the wave-per-pixel forward kernel (M >= 1024)
     (16, 16, 16, 64, 1, 4, 2),     # pix2pix m5 geometry at 64 channels
     (5, 15, 17, 24, 1, 3, 1),      # stride 1, odd sizes, C / 8 = 3 chunks per tap
@@ -448,7 +452,8 @@ def test_pack_filters_batch_equals_single_packs_and_timing_records():
 
 
 @pytest.mark.parametrize('dtype', [0, 1])
-@pytest.mark.parametrize('case', [(6, 16, 16, 200, 400, 5, 2, 4), (5, 8, 8, 40, 104, 5, 2, 2), (4, 32, 32, 3, 200, 5, 2, 3)])
+@pytest.mark.parametrize('case', [(6, 16, 16, 200, 400, 5, 2, 4), (5, 8, 8, 40, 104, 5, 2, 2), (4, 32, 32, 3, 200, 5, 2, 3),
+                                  (6, 16, 16, 64, 256, 4, 2, 2)])      # the last: 256-column LDS-DMA tile
 def test_bwd_filter_two_sources(case, dtype):
     """tdg_conv2d_bwd_filter2 (rows of the first n_first images from one tensor, the rest from another) against the
     oracle's conv2d_backprop_filter on the concatenated input, with accumulation into an existing dw."""
