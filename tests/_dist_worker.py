@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_distributed.py: one replica of a 2-replica run (launched by torch.distributed.run) of iwgan, wgan or vae.
+"""Worker of tests/test_gpu_distributed.py: one replica of a 2-replica run (launched by torch.distributed.run) of iwgan, wgan, vae or pix2pix.
 Both replicas are given the SAME data, seed and RNG key (Session(rank=0)), so the mean over replicas equals each
 replica's own gradient exactly and the variables must match a single-replica run bit for bit."""
 import importlib
@@ -35,6 +35,15 @@ def run(out_path, world, model='iwgan'):
                                lr=1e-3, beta1=0.9, beta2=0.999, decay=0.9, momentum=0.01, centered=False, use_graphs=True)
         rep = vae.VaeReplica(data.SyntheticSource(6 * B, shape, B, sess.device, 5, 0), args, sess)
         stores = [rep.store]
+    elif model == 'pix2pix':                                  # config 4's model: two nets, one exchange per optimizer step
+        p2p = importlib.import_module('3dgan_amd.models.pix2pix')
+        B = 1
+        args = SimpleNamespace(model='pix2pix', batch_size=B, n_gpus=world, optimizer='adam', lr=1e-4, beta1=0.5, beta2=0.999, decay=0.9,
+                               momentum=0.01, centered=False, n_disc_train=1, skip_layers=True, noise=[], dropout=0, batch_norm_disc=False,
+                               batch_norm_gen=False, add_l1=True, seed=3, use_graphs=True)
+        rep = p2p.pix2pix(data.SyntheticPairSource(3, B, sess.device, seed=5, rank=0), args, sess)
+        rep.train_func = lambda: rep.train(sess, args, None)
+        stores = rep.stores()
     else:                                                     # iwgan (split critic exchange) / wgan (config 3's model: rmsprop, one exchange)
         gan = importlib.import_module('3dgan_amd.models.gan')
         B, L, shape = 8, 16, (32, 32, 3)

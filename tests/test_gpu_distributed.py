@@ -14,9 +14,10 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('model,port', [('iwgan', 29533), ('wgan', 29534), ('vae', 29535)])
+@pytest.mark.parametrize('model,port', [('iwgan', 29533), ('wgan', 29534), ('vae', 29535), ('pix2pix', 29536)])
 def test_two_replicas_match_one(tmp_path, model, port):
-    """iwgan: the headline schedule; wgan: config 3's model (rmsprop, one exchange per step); vae: config 5's model."""
+    """iwgan: the headline schedule; wgan: config 3's model (rmsprop, one exchange per step); vae: config 5's model; pix2pix: config 4's
+    (256 x 256, one pair per replica)."""
     worker = os.path.join(ROOT, 'tests', '_dist_worker.py')
     env = dict(os.environ, TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
