@@ -309,21 +309,23 @@ struct FinArgs {
   float* out1;          // bwd: mean sums [2][C] for the apply pass
   float beta_acc;
 };
-// 8 channels x 32 partial lanes per block (C/8 blocks: enough workgroups and short enough per-thread chains for up to
-// 1024 row blocks); fixed summation order (deterministic)
+// CH channels x 256 / CH partial lanes per block: 8 x 32 for up to ~1k row blocks (C / 8 workgroups, short per-thread chains); 2 x 128
+// for the thousands of row tiles a GEMM epilogue reports on pix2pix's 128 x 128 / 256 x 256 layers (the 8 x 32 form: 9 - 20 us on
+// 8 - 64 workgroups).  Fixed summation order (deterministic).
 #define FIN_CH 8
-template <typename T, int MODE>
+template <typename T, int MODE, int CH>
 __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
-  __shared__ float sh[2][32][FIN_CH];
-  const int tx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x / FIN_CH;
-  const int c = blockIdx.x * FIN_CH + tx;
+  constexpr int RL = 256 / CH;
+  __shared__ float sh[2][RL][CH];
+  const int tx = threadIdx.x & (CH - 1), ty = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + tx;
   float s0 = 0.f, s1 = 0.f;
   if (c < a.C)
-    for (int b0 = ty; b0 < a.nblk; b0 += 4 * 32) {
+    for (int b0 = ty; b0 < a.nblk; b0 += 4 * RL) {
       float p0[4], p1[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const int b = b0 + 32 * u;
+        const int b = b0 + RL * u;
         const bool ok = b < a.nblk;
         p0[u] = ok ? a.partial[((size_t)b * 2 + 0) * a.C + c] : 0.f;
         p1[u] = (ok && MODE != FIN_ACC) ? a.partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
@@ -337,7 +339,7 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   if (ty != 0 || c >= a.C) return;
   s0 = s1 = 0.f;
 #pragma unroll
-  for (int k = 0; k < 32; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
+  for (int k = 0; k < RL; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
   const float inv = 1.f / (float)a.rows;
   if (MODE == FIN_BN_STATS) {
     const float pivot = a.pivot_f ? a.pivot_f[c] : (a.x0 ? to_f32<T>(static_cast<const T*>(a.x0)[c]) : 0.f);
@@ -355,6 +357,13 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   } else {
     a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
   }
+}
+template <typename T, int MODE>
+static void launch_col_finalize(const FinArgs& f, hipStream_t s) {
+  if (f.nblk >= 1024)
+    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, 2>), dim3((f.C + 1) / 2), dim3(256), 0, s, f);
+  else
+    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, FIN_CH>), dim3((f.C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
 }
 
 template <typename T, int VW>
@@ -479,7 +488,7 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_STATS>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    launch_col_finalize<T, FIN_BN_STATS>(f, s);
     if (ga.vw == 4)
       hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
                          leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
@@ -495,7 +504,7 @@ extern "C" int tdg_col_finalize_sum(const float* partial, int nblk, int c, float
   TDG_CHECK_ARG(partial && out && nblk > 0 && c > 0, "tdg_col_finalize_sum: bad argument");
   FinArgs f; memset(&f, 0, sizeof(f));
   f.partial = partial; f.nblk = nblk; f.C = c; f.rows = 1; f.out0 = out; f.beta_acc = beta;
-  hipLaunchKernelGGL((col_finalize_kernel<float, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, f);
+  launch_col_finalize<float, FIN_ACC>(f, (hipStream_t)stream);
   TDG_HIP_LAUNCH_CHECK("col_finalize_sum");
   return TDG_OK;
 }
@@ -511,7 +520,7 @@ extern "C" int tdg_bn_fwd_from_partials(int dtype, const void* u, int rows, int 
   const ColGeom ga = col_geom(rows, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), tdg_dtype_size(dtype), h_cs % 4 == 0);
   const dim3 agrid(apply_row_blocks(ga), ga.ncol);
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_STATS>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    launch_col_finalize<T, FIN_BN_STATS>(f, s);
     if (ga.vw == 4)
       hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
                          leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
@@ -547,7 +556,7 @@ extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_BN_BWD>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_BN_BWD>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    launch_col_finalize<T, FIN_BN_BWD>(f, s);
     if (dbias) {
       if (ga.vw == 4)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, true>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
@@ -555,7 +564,7 @@ extern "C" int tdg_bn_bwd(int dtype, const void* dh, int dh_cs, const void* pre,
       else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, true>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
                            static_cast<const T*>(pre), beta, stats, sums, act, leak, static_cast<T*>(du), a.partial);
-      hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, fb);
+      launch_col_finalize<T, FIN_ACC>(fb, s);
     } else {
       if (ga.vw == 4)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, false>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(dh), dh_cs,
@@ -582,7 +591,7 @@ extern "C" int tdg_bias_grad(int dtype, const void* dy, int rows, int c, int cs,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_SUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    launch_col_finalize<T, FIN_ACC>(f, s);
   })
   TDG_HIP_LAUNCH_CHECK("bias_grad");
   return TDG_OK;
@@ -601,7 +610,7 @@ extern "C" int tdg_colsum_weighted(int dtype, const void* x, int rows, int cols,
   DISPATCH_T(dtype, {
     int rc = run_col_partial<T, COL_WSUM>(g, a, s);
     if (rc) return rc;
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC>), dim3((cols + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    launch_col_finalize<T, FIN_ACC>(f, s);
   })
   TDG_HIP_LAUNCH_CHECK("colsum_weighted");
   return TDG_OK;
@@ -695,7 +704,7 @@ extern "C" int tdg_instance_norm_bwd(int dtype, const void* dh, int dh_cs, const
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(instance_norm_bwd_kernel<T>, dim3(n, (c + 63) / 64), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(dh),
                        dh_cs, static_cast<const T*>(u), hw, c, cs, scale, shift, stats, act, leak, static_cast<T*>(du), part);
-    hipLaunchKernelGGL((col_finalize_kernel<T, FIN_ACC2>), dim3((c + FIN_CH - 1) / FIN_CH), dim3(256), 0, (hipStream_t)stream, f);
+    launch_col_finalize<T, FIN_ACC2>(f, (hipStream_t)stream);
   })
   TDG_HIP_LAUNCH_CHECK("instance_norm_bwd");
   return TDG_OK;
