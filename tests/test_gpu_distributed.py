@@ -72,3 +72,19 @@ def test_rccl_runs_the_exchange_path(tmp_path, model):
     for k in a.files:
         assert np.all(np.isfinite(a[k])), k
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_train_cli_launches_its_replicas(tmp_path):
+    """`python train.py --n_gpus 2` (the reference's flag, train.py:262) starts one process per replica itself, trains an epoch and
+    leaves rank 0's checkpoint + options.config behind (gloo standing in for RCCL on the one-GPU box)."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    d = str(tmp_path / 'ws')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--model', 'iwgan', '--batch_size', '8', '--latent_size', '16',
+                        '--optimizer', 'adam', '--lr', '1e-4', '--beta1', '0.5', '--beta2', '0.9', '--dataset', 'synthetic',
+                        '--epoch_size', '3', '--epochs', '1', '--n_gpus', '2', '--dir', d],
+                       env=env, timeout=900, capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    assert 'Training complete' in p.stdout
+    found = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs]
+    assert any(f.endswith('options.config') for f in found) and any('checkpoint' in os.path.basename(f) for f in found), found
