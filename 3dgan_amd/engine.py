@@ -31,7 +31,8 @@ class GraphRunner:
     host reads stay outside the captured bodies."""
 
     def init_graphs(self, args, sess):
-        self.use_graphs = bool(getattr(args, 'use_graphs', True)) and sess.device.type == 'cuda' and not sess.check_numerics
+        # (--check_numerics keeps the graphs: the finite check runs between the captured bodies, never inside one)
+        self.use_graphs = bool(getattr(args, 'use_graphs', True)) and sess.device.type == 'cuda'
         self._warm, self._graphs = set(), {}
 
     def _run(self, name, body):

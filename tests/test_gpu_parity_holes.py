@@ -95,7 +95,7 @@ def test_check_numerics_names_the_variable():
             def next_batch(self):
                 return torch.tensor(rng.uniform(0, 1, (4, 32, 32, 3)).astype(np.float32), device=dev)
         rep = gan.GanReplica(Src(), args, sess)
-        assert rep.use_graphs is (not check)                 # the finite check needs a host read between grads and apply
+        assert rep.use_graphs                                # the finite check runs BETWEEN the captured bodies: the graphs stay on
         rep.d_store['discriminator/vars/c3/weights'].view(-1)[5] = float('nan')
         rep.refresh()
         before = rep.d_store['discriminator/vars/c1/weights'].clone()
@@ -108,6 +108,17 @@ def test_check_numerics_names_the_variable():
         else:
             rep.d_step(Src().next_batch())
             assert sess.global_step == 1
+    # a NaN that appears AFTER the bodies were captured is caught in a replayed step as well
+    args = make_args('iwgan', 4, 8, (32, 32, 3))
+    sess = rt.Session(device=dev, dtype=0, seed=0, rank=0, world_size=1, check_numerics=True)
+    rep = gan.GanReplica(Src(), args, sess)
+    for _ in range(3):
+        rep.d_step(Src().next_batch())                       # eager, capture, replay
+    rep.d_store['discriminator/vars/c2/weights'].view(-1)[7] = float('inf')
+    rep.refresh()
+    with pytest.raises(FloatingPointError):
+        rep.d_step(Src().next_batch())
+    assert sess.global_step == 3
 
 
 # ------------------------------------------------------------------------------------------------ resume
