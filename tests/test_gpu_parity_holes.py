@@ -255,3 +255,19 @@ def test_epoch_summaries_from_a_live_replica(tmp_path):
         for j in (0, 3, 7):
             for r in (0, 5):
                 assert np.array_equal(img[j * 32:(j + 1) * 32, r * 32:(r + 1) * 32], want[j * 8 + r])
+
+
+def test_training_failure_leaves_with_the_gen2_status(tmp_path):
+    """hem/util/training.py:173-175: an exception inside the training loop is reported and the process leaves with -1 (255), the
+    status repeat.sh restarts on.  Here: --check_numerics under an absurd learning rate (the second critic step sees Inf weights)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--model', 'iwgan', '--batch_size', '8', '--latent_size', '16',
+                        '--optimizer', 'sgd', '--lr', '1e30', '--dataset', 'synthetic', '--epoch_size', '4', '--epochs', '1',
+                        '--check_numerics', '--dir', str(tmp_path / 'ws')], env=env, timeout=600, capture_output=True, text=True)
+    assert p.returncode == 255, (p.returncode, p.stdout[-800:], p.stderr[-1500:])
+    assert 'Caught unexpected exception during training: FloatingPointError' in p.stdout
+    assert 'discriminator/vars/' in p.stdout or 'generator/vars/' in p.stdout

@@ -146,20 +146,26 @@ def main(argv=None):
         ckpt.save(os.path.join(args.dir, 'checkpoint-0.npz'), replica, sess)                           # train.py:288-291
     if chief:
         message('Starting training...')
-    for epoch in range(current_epoch, max_epochs):
-        it = range(iter_per_epoch)
-        pbar = tqdm(it, desc='Epoch {:3d}'.format(epoch + 1), unit='batch') if chief else it
-        for i in pbar:
-            prev_status = status
-            status = train_func(sess, args)                                                            # train.py:307
+    try:
+        for epoch in range(current_epoch, max_epochs):
+            it = range(iter_per_epoch)
+            pbar = tqdm(it, desc='Epoch {:3d}'.format(epoch + 1), unit='batch') if chief else it
+            for i in pbar:
+                prev_status = status
+                status = train_func(sess, args)                                                        # train.py:307
+                if chief:
+                    pbar.set_postfix(util.format_for_terminal(dict(status), prev_status))
+            sess.global_epoch += 1                                                                     # train.py:322
             if chief:
-                pbar.set_postfix(util.format_for_terminal(dict(status), prev_status))
-        sess.global_epoch += 1                                                                         # train.py:322
-        if chief:
-            real, fake = replica.samples(args.examples) if hasattr(replica, 'samples') else (None, None)
-            summaries.write_epoch(os.path.join(args.dir, 'summaries'), sess.global_epoch, status or {}, real, fake,
-                                  args.examples)                                                       # models/gan.py:93-107
-            ckpt.save(os.path.join(args.dir, 'checkpoint-{}.npz'.format(sess.global_epoch)), replica, sess)   # :329
+                real, fake = replica.samples(args.examples) if hasattr(replica, 'samples') else (None, None)
+                summaries.write_epoch(os.path.join(args.dir, 'summaries'), sess.global_epoch, status or {}, real, fake,
+                                      args.examples)                                                   # models/gan.py:93-107
+                ckpt.save(os.path.join(args.dir, 'checkpoint-{}.npz'.format(sess.global_epoch)), replica, sess)   # :329
+    except Exception as e:
+        # gen-2's convention (hem/util/training.py:173-175): report and leave with -1, the status repeat.sh restarts on
+        # (it resumes from the newest checkpoint in --dir); the library's status text travels in the exception
+        print('Caught unexpected exception during training:', type(e).__name__, e, flush=True)
+        sys.exit(-1)
     if chief:
         message('\nTraining complete! Elapsed time: {}s'.format(int(time.time() - start_time)))
     if world > 1:
