@@ -64,7 +64,7 @@ def build_parser():
         help='gen-1: read a file of `key value` pairs; command line arguments overwrite it.')
     add('--seed', type=int, help='Randomized each execution if not set.')
     add('--n_gpus', type=int, default=1, help='Number of GPUs (one replica process per GPU).')
-    add('--profile', default=False, action='store_true', help='Accepted for compatibility (dead flag in the reference).')
+    add('--profile', default=False, action='store_true', help='Write <dir>/profile.txt: the conv GEMM kernels of one training iteration (a dead flag in the reference).')
     add('--check_numerics', default=False, action='store_true', help='Fail with the variable name on NaN/Inf gradients.')
     add('--precision', default='bf16', choices=['bf16', 'f32'],
         help='bf16 MFMA with f32 accumulate / master weights (throughput) or exact f32 (parity).')

@@ -271,3 +271,19 @@ def test_training_failure_leaves_with_the_gen2_status(tmp_path):
     assert p.returncode == 255, (p.returncode, p.stdout[-800:], p.stderr[-1500:])
     assert 'Caught unexpected exception during training: FloatingPointError' in p.stdout
     assert 'discriminator/vars/' in p.stdout or 'generator/vars/' in p.stdout
+
+
+def test_profile_flag_writes_a_kernel_table(tmp_path):
+    """--profile (train.py:75,264-265: parsed, never used by the reference): here one iteration's conv GEMM kernels."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    d = str(tmp_path / 'ws')
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--model', 'iwgan', '--batch_size', '8', '--latent_size', '16',
+                        '--optimizer', 'adam', '--lr', '1e-4', '--dataset', 'synthetic', '--epoch_size', '5', '--epochs', '1', '--profile',
+                        '--dir', d], env=env, timeout=600, capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[-800:], p.stderr[-1500:])
+    text = open(os.path.join(d, 'profile.txt')).read()
+    assert 'igemm' in text and 'TFLOP/s' in text and 'total' in text

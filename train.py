@@ -152,7 +152,14 @@ def main(argv=None):
             pbar = tqdm(it, desc='Epoch {:3d}'.format(epoch + 1), unit='batch') if chief else it
             for i in pbar:
                 prev_status = status
+                profiled = args.profile and chief and epoch == current_epoch and i == min(3, iter_per_epoch - 1)
+                if profiled:                     # --profile: one iteration run eagerly with the library's per-launch HIP events
+                    graphs, replica.use_graphs = getattr(replica, 'use_graphs', False), False
+                    K.timing_begin()
                 status = train_func(sess, args)                                                        # train.py:307
+                if profiled:
+                    write_profile(os.path.join(args.dir, 'profile.txt'), K.timing_end())
+                    replica.use_graphs = graphs
                 if chief:
                     pbar.set_postfix(util.format_for_terminal(dict(status), prev_status))
             sess.global_epoch += 1                                                                     # train.py:322
@@ -171,6 +178,23 @@ def main(argv=None):
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+
+
+def write_profile(path, records):
+    """--profile (a dead flag in the reference: train.py:264-265 builds RunOptions that no sess.run receives): the conv GEMM
+    launches of one training iteration, per kernel -- launches, milliseconds, algorithmic TFLOP/s."""
+    acc = {}
+    for name, ms, flops in records:
+        e = acc.setdefault(name, [0, 0.0, 0.0])
+        e[0] += 1
+        e[1] += ms
+        e[2] += flops
+    with open(path, 'w') as f:
+        f.write('%-48s %8s %10s %9s\n' % ('kernel', 'launches', 'ms', 'TFLOP/s'))
+        for name, (n, ms, fl) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            f.write('%-48s %8d %10.3f %9.1f\n' % (name, n, ms, fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0))
+        f.write('%-48s %8d %10.3f\n' % ('total (conv GEMM kernels of one iteration)', sum(v[0] for v in acc.values()),
+                                       sum(v[1] for v in acc.values())))
 
 
 if __name__ == '__main__':
