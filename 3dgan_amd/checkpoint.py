@@ -51,3 +51,22 @@ def restore(path, replica, sess):
         sess.set_rng_state(int(z['rng/draws']))
     if hasattr(replica, 'refresh'):
         replica.refresh()                            # packed GEMM operands follow the restored masters
+
+
+def prune(directory, max_to_keep):
+    """gen-2's `--max_to_keep N` (hem/util/misc.py:148: tf.train.Saver(max_to_keep=N)): keep the N most recent `checkpoint-<n>.npz`
+    of `directory`; 0 keeps every one (gen-1's train.py:259)."""
+    import glob
+    import re
+    if not max_to_keep or max_to_keep <= 0:
+        return []
+    found = []
+    for f in glob.glob(os.path.join(directory, 'checkpoint-*.npz')):
+        m = re.search(r'checkpoint-(\d+)\.npz$', f)
+        if m:
+            found.append((int(m.group(1)), f))
+    found.sort()
+    gone = [f for _, f in found[:-max_to_keep]]
+    for f in gone:
+        os.remove(f)
+    return gone

@@ -221,3 +221,15 @@ def test_lambda_activation_is_traced_to_a_fused_epilogue():
             Lm.conv2d(x, 4, 8, 3, 1, activation=lambda t: t, name='c')
     a, b = net.layers[0], net.layers[1]
     assert (a.act.code, a.act.leak) == (lib.ACT_LRELU, 0.1) and b.act.code == lib.ACT_RELU
+
+
+def test_checkpoint_retention(tmp_path):
+    """gen-2 --max_to_keep N keeps the N newest checkpoint-<n>.npz (numeric order, not lexical); 0 keeps all."""
+    ck = pkg('checkpoint')
+    for n in (0, 1, 2, 9, 10, 11):
+        (tmp_path / ('checkpoint-%d.npz' % n)).write_bytes(b'x')
+    (tmp_path / 'options.config').write_text('a 1\n')
+    assert ck.prune(str(tmp_path), 0) == []
+    gone = ck.prune(str(tmp_path), 2)
+    assert sorted(os.path.basename(f) for f in gone) == ['checkpoint-0.npz', 'checkpoint-1.npz', 'checkpoint-2.npz', 'checkpoint-9.npz']
+    assert sorted(os.listdir(tmp_path)) == ['checkpoint-10.npz', 'checkpoint-11.npz', 'options.config']

@@ -168,6 +168,7 @@ def main(argv=None):
                 summaries.write_epoch(os.path.join(args.dir, 'summaries'), sess.global_epoch, status or {}, real, fake,
                                       args.examples)                                                   # models/gan.py:93-107
                 ckpt.save(os.path.join(args.dir, 'checkpoint-{}.npz'.format(sess.global_epoch)), replica, sess)   # :329
+                ckpt.prune(args.dir, getattr(args, 'max_to_keep', 0))                                   # gen-2 --max_to_keep
     except Exception as e:
         # gen-2's convention (hem/util/training.py:173-175): report and leave with -1, the status repeat.sh restarts on
         # (it resumes from the newest checkpoint in --dir); the library's status text travels in the exception
