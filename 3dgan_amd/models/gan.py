@@ -245,7 +245,13 @@ class GanReplica(engine.GraphRunner):
     def big_slice(self):
         """[lo, hi) of the critic's flat bucket holding its largest filter and that layer's bias (adjacent variables)."""
         big, store = self._d_big_layer, self.d_store
-        return store.index[big.wname][0], store.index[big.bname][0] + (big.spec.out_size + 3) // 4 * 4
+        lo, hi = store.index[big.wname][0], store.index[big.bname][0] + (big.spec.out_size + 3) // 4 * 4
+        # the variables declared behind it belong to fc2 (a row kernel: its gradients are complete before any conv filter
+        # gradient is taken), so the slice runs to the end of the bucket: two collectives per critic step instead of three
+        # (the third was a 51 KB one paying a full collective latency)
+        if all(L.rowdot for L in self.D.layers[big.idx + 1:]) and self.D.n_bn_passes == 1 and not any(L.spec.normed for L in self.D.layers):
+            hi = store.size
+        return lo, hi
 
     # -- steps -------------------------------------------------------------------------------------
     def d_step(self, x01):
@@ -257,7 +263,7 @@ class GanReplica(engine.GraphRunner):
         the bucket follows.  One replica: a single captured body, no exchange."""
         self._load_real(x01)
         sess, store = self.sess, self.d_store
-        if sess.world_size > 1 and self.iwgan:
+        if sess.world_size > 1 and self.iwgan and os.environ.get('TDG_DSPLIT', '1') != '0':      # (TDG_DSPLIT=0, diagnostics: one body, one exchange)
             lo, hi = self.big_slice()
             self._run('d_grads_a', self._d_grads_a)
             self._scale = sess.allreduce_split(store.grads, lo, hi, between=lambda: self._run('d_grads_b', self._d_grads_b))
@@ -330,7 +336,7 @@ class GanReplica(engine.GraphRunner):
         if self.display_d_loss:
             self._load_real(x01)
         sess, store = self.sess, self.g_store
-        if sess.world_size > 1 and self.iwgan and self.display_d_loss:
+        if sess.world_size > 1 and self.iwgan and self.display_d_loss and os.environ.get('TDG_GSPLIT', '1') != '0':   # (diagnostics)
             self._run('g_grads_a', self._g_grads_critical)
             work = sess.allreduce_async(store.grads)
             self._run('g_grads_b', self._g_display_d_loss)
