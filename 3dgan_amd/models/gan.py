@@ -186,12 +186,12 @@ class GanReplica(engine.GraphRunner):
         both = view[:, :n, :, :, :c].float().cpu().numpy()
         return both[0], both[1]
 
-    def _interpolate(self):
-        """models/gan.py:224-226 into slot 2."""
+    def _interpolate(self, out_slot=2):
+        """models/gan.py:224-226 into slot 2 (or, elementwise in place, over g in slot 1 once nothing reads g any more)."""
         B = self.B
         self.sess.random_uniform(self.alpha, B, 'alpha')
         _lib.call('tdg_gp_interp', self.sess.dtype, self.D.x.ptr(0), self.D.x.ptr(B), K.ptr(self.alpha), B,
-                  self.img_elems, self.D.x.ptr(2 * B), K.stream())
+                  self.img_elems, self.D.x.ptr(out_slot * B), K.stream())
 
     def _d_forward(self, first_slot, nslots):
         B = self.B
@@ -222,7 +222,7 @@ class GanReplica(engine.GraphRunner):
             bufs[values] = buf
         self.D.layers[-1].seed = buf
 
-    def _penalty_from_v(self, tangent_seed=False):
+    def _penalty_from_v(self, tangent_seed=False, slot=2):
         """slopes = sqrt(sum over the WHOLE batch tensor) (models/gan.py:229), penalty (:230).  With `tangent_seed` also
         u = d(lambda * penalty)/dv into the tangent pass's input.  --gp_per_sample (opt-in, App. C-4): one norm per image,
         penalty = mean_i (|v_i| - 1)^2."""
@@ -232,14 +232,14 @@ class GanReplica(engine.GraphRunner):
                 self._pen_rows = torch.zeros(B, dtype=torch.float32, device=self.sess.device)
                 self._u_sink = K.Act(B, *self.args.image_shape, self.sess.dtype, self.sess.device) if not self.D.tangent_capacity else None
             u = self.D.tan_in if self.D.tangent_capacity else self._u_sink
-            _lib.call('tdg_gp_rows', self.sess.dtype, self.D.dx.ptr(2 * B), B, self.img_elems, GP_LAMBDA, K.ptr(self._pen_rows),
+            _lib.call('tdg_gp_rows', self.sess.dtype, self.D.dx.ptr(slot * B), B, self.img_elems, GP_LAMBDA, K.ptr(self._pen_rows),
                       u.ptr(0), K.stream())
             _lib.call('tdg_mean_f32', K.ptr(self._pen_rows), B, K.ptr(self.scal, 4 * self.S_GP), K.stream())
             return
-        K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
+        K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(slot * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
         _lib.call('tdg_gp_scalars', K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA, K.ptr(self.scal, 4 * self.S_GP), K.stream())
         if tangent_seed:
-            _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(2 * B), B * self.img_elems,
+            _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(slot * B), B * self.img_elems,
                       K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())
 
     def big_slice(self):
@@ -364,13 +364,14 @@ class GanReplica(engine.GraphRunner):
         """The reported d_loss (models/gan.py:199-205 fetched beside g_train_op): D(x), D(x_hat), the penalty."""
         B, R = self.B, self.B * self.rows_per_image
         self._rescale_real()
-        self._interpolate()
-        self._d_forward(0, 1)
-        scores = self._d_forward(2, 1)
+        # g (slot 1) has served the gradient path above: x_hat takes its place, so that D(x) and D(x_hat) are ONE batched pass
+        # over the adjacent slots 0 and 1 (two separate 512-image passes cost 0.1 ms more per iteration)
+        self._interpolate(out_slot=1)
+        scores = self._d_forward(0, 2)
         _lib.call('tdg_mean_f32', K.ptr(scores, 0), R, K.ptr(self.scal, 4 * self.S_DREAL), K.stream())
-        self._seeds(None, None, 1.0)
-        self.D.backward(2 * B, B, want_params=False, want_dx=True)
-        self._penalty_from_v()
+        self._seeds(None, 1.0)
+        self.D.backward(B, B, want_params=False, want_dx=True)
+        self._penalty_from_v(slot=1)
 
     def _g_grads(self):
         B, R = self.B, self.B * self.rows_per_image
