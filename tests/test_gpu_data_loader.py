@@ -91,3 +91,30 @@ def test_train_cli_on_cifar_pickles(tmp_path):
     out = p.stdout + p.stderr
     assert '25/25' in out.replace(' ', ''), out[-1500:]          # 200 images // 8
     assert 'nan' not in out.lower().split('starting training')[-1]
+
+
+def test_train_cli_pix2pix_on_nyuv2_png_records(tmp_path):
+    """Config 4's real input path end to end (hem/data/nyuv2.py:148-262 -> hem/models/pix2pix.py): PNG records (8-bit RGB image,
+    16-bit depth) in `nyuv2.train.tfrecords`, decoded by the plugin, one 256 x 256 crop window per pair, served from HBM to the
+    pix2pix step through `train.py @config`-style flags."""
+    from test_host_gen2 import _png_encode
+    tfr = pkg('tfrecord')
+    rng = np.random.default_rng(4)
+    recs = []
+    for i in range(5):
+        rgb = rng.integers(0, 256, (260, 264, 3), dtype=np.uint8)
+        depth = rng.integers(1000, 60000, (260, 264, 1), dtype=np.uint16)
+        recs.append(tfr.make_example({'image': _png_encode(rgb, [1, 2, 4]), 'depth': _png_encode(depth, [2, 0]),
+                                      'width': 260, 'height': 264, 'channels': 3}))
+    d = tmp_path / 'datasets'
+    d.mkdir()
+    tfr.write_records(str(d / 'nyuv2.train.tfrecords'), recs)
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'train.py'), '--model', 'pix2pix', '--dataset', 'nyuv2', '--dataset_dir', str(d),
+                        '--cache_dir', str(tmp_path / 'cache'), '--random_crop', '256', '256', '--batch_size', '2', '--optimizer', 'adam',
+                        '--lr', '1e-4', '--beta1', '0.5', '--n_disc_train', '1', '--skip_layers', '--epochs', '1',
+                        '--dir', str(tmp_path / 'ws')], env=env, timeout=900, capture_output=True, text=True)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = p.stdout + p.stderr
+    assert 'Training complete' in out and '2/2' in out.replace(' ', ''), out[-1500:]          # 5 pairs // 2
+    assert 'nan' not in out.lower().split('starting training')[-1]
