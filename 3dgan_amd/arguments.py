@@ -136,10 +136,13 @@ def parse_args(argv=None, display=False, warn=None):
     if args.model in models:
         for k, v in models[args.model].arguments().items():
             kw = dict(v)
-            if k == '--n_disc_train' and args.n_disc_train is not None:
-                kw['default'] = args.n_disc_train        # already given in an earlier pass: the plugin default must not undo it
-            if k == '--examples':
-                kw['default'] = args.examples
+            dest = kw.get('dest') or k.lstrip('-').replace('-', '_')
+            if hasattr(args, dest):
+                if getattr(args, dest) is None:
+                    delattr(args, dest)                  # declared by an earlier pass but never given: argparse applies a default
+                                                         # only to a dest the namespace lacks, so make room for the plugin's
+                else:
+                    kw['default'] = getattr(args, dest)  # given (or defaulted to a value) earlier: the plugin must not undo it
             parser.add_argument(k, **kw)
         args, leftover = parser.parse_known_args(leftover, namespace=args)
     elif args.model not in GEN1_MODELS and args.model != 'fc':

@@ -118,10 +118,29 @@ __device__ __forceinline__ float block_sum256(float v, float* sh /*>=4*/) {
 #define TICKET_SUMSQ 1024
 #define TICKET_ADAM 1025
 #define TICKET_RNG 1026
-#define TICKET_L1 1027
 #define TICKET_ADAM_SUB 1088
 #define TICKET_RNG_SUB 1152
 __device__ unsigned g_ticket[1216];
+
+// The slots are per PROCESS, one per kernel family, so two launches of one family must never overlap on the device.  One
+// stream guarantees that; the library therefore refuses a ticketed launch on a second stream (a stream under hipGraph
+// capture is exempt: the captured launches replay in their captured order on whatever stream launches the graph, which
+// the same rule covers).  Entry points concerned: tdg_sumsq, tdg_adam_step_dev, tdg_random_normal_dev,
+// tdg_random_uniform_f32_dev (include/tdg.h says so at each).
+static int ticket_stream_check(const char* who, void* stream) {
+  static hipStream_t first = nullptr;
+  static bool have = false;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return TDG_OK;
+  if (!have) { first = (hipStream_t)stream; have = true; return TDG_OK; }
+  if (first != (hipStream_t)stream) {
+    tdg_set_error("%s: launched on stream %p, but kernels that take last-block tickets first ran on stream %p -- their "
+                  "device-global ticket slots allow ONE stream per process", who, stream, (void*)first);
+    return TDG_EINVAL;
+  }
+  return TDG_OK;
+}
+#define TDG_TICKET_STREAM(who, stream) do { const int rc__ = ticket_stream_check(who, stream); if (rc__ != TDG_OK) return rc__; } while (0)
 
 // Two levels above 64 blocks: 4096 tickets on ONE word cost ~46 us (a word takes ~88 atomics per us); 64 sub-counters of
 // <= 64 tickets each plus 64 tickets on the top word cost ~1.5 us.
@@ -1060,6 +1079,7 @@ extern "C" int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float b
                          size_t workspace_bytes, void* stream) {
   TDG_CHECK_ARG(x && acc && workspace && n > 0, "tdg_sumsq: bad argument");
   if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_sumsq: workspace too small"); return TDG_EWORKSPACE; }
+  TDG_TICKET_STREAM("tdg_sumsq", stream);
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(x),
                        n, static_cast<float*>(workspace), acc, beta);
@@ -1477,6 +1497,7 @@ __global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, co
 extern "C" int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                                  float eps, float grad_scale, int32_t* t_dev, void* stream) {
   TDG_CHECK_ARG(p && g && m && v && t_dev && n > 0 && (n & 3) == 0, "tdg_adam_step_dev: bad argument (n must be a multiple of 4)");
+  TDG_TICKET_STREAM("tdg_adam_step_dev", stream);
   hipLaunchKernelGGL(adam_dev_kernel, dim3(ew_blocks(n / 4, 512)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
                      beta1, beta2, eps, grad_scale, t_dev);
   TDG_HIP_LAUNCH_CHECK("adam_dev");
@@ -1724,6 +1745,7 @@ extern "C" int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, u
 extern "C" int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, void* out,
                                      void* stream) {
   TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_normal_dev: bad argument");
+  TDG_TICKET_STREAM("tdg_random_normal_dev", stream);
   DISPATCH_T(dtype, {
     hipLaunchKernelGGL(random_normal_kernel<T>, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
                        stream_id, (uint64_t)0, draw_dev, n, static_cast<T*>(out));
@@ -1755,6 +1777,7 @@ extern "C" int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_
 extern "C" int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, float* out,
                                           void* stream) {
   TDG_CHECK_ARG(out && draw_dev && n > 0, "tdg_random_uniform_f32_dev: bad argument");
+  TDG_TICKET_STREAM("tdg_random_uniform_f32_dev", stream);
   hipLaunchKernelGGL(random_uniform_kernel, dim3(ew_blocks((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, seed,
                      stream_id, (uint64_t)0, draw_dev, n, out);
   TDG_HIP_LAUNCH_CHECK("random_uniform_dev");

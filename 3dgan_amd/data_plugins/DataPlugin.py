@@ -44,3 +44,17 @@ def find_file(args, names):
             if os.path.exists(p):
                 return p
     return None
+
+
+def write_cache_atomically(path, write):
+    """`write(file_object)` into a per-process temporary file beside `path`, then os.replace: with `--n_gpus > 1` every
+    replica process decodes and caches the same dataset, and a late starter must find either no cache or a whole one."""
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    tmp = '%s.%d.tmp' % (path, os.getpid())
+    try:
+        with open(tmp, 'wb') as f:
+            write(f)
+        os.replace(tmp, path)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)

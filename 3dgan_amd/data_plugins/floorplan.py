@@ -10,7 +10,7 @@ import os
 import numpy as np
 import torch
 
-from .DataPlugin import DataPlugin, find_file, dataset_dirs
+from .DataPlugin import DataPlugin, find_file, dataset_dirs, write_cache_atomically
 from ._common import finish_images, resize_bilinear_tf1
 from .. import tfrecord, png
 
@@ -44,8 +44,7 @@ class FloorplanDataset(DataPlugin):
             out.append(np.clip(np.rint(x[0].numpy()), 0, 255).astype(np.uint8))
         imgs = np.stack(out)
         if cache:
-            os.makedirs(args.cache_dir, exist_ok=True)
-            np.save(cache, imgs)
+            write_cache_atomically(cache, lambda f: np.save(f, imgs))
         return imgs
 
     @staticmethod

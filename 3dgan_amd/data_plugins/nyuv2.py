@@ -16,7 +16,7 @@ import sys
 import numpy as np
 import torch
 
-from .DataPlugin import DataPlugin, find_file, dataset_dirs
+from .DataPlugin import DataPlugin, find_file, dataset_dirs, write_cache_atomically
 from ._common import resize_bilinear_tf1
 from .. import tfrecord, png
 
@@ -33,8 +33,20 @@ class PairSource:
         self.B, self.device, self.crop, self.resize = batch_size, device, crop, resize
         self.gen = torch.Generator(device='cpu').manual_seed(int(seed) + 7919 * rank)
         self.n = self.rgb.shape[0]
+        self.barren_passes = 8                       # give up after this many passes over the shard without ONE valid crop
+        if not crop:
+            # without a random window a frame's verdict never changes: decide once, then draw only frames that pass
+            # (the reference's filter is unbounded, hem/data/nyuv2.py:258-266; re-testing them every epoch is not)
+            keep = []
+            for i0 in range(0, self.n, 64):
+                idx = torch.arange(i0, min(i0 + 64, self.n))
+                keep.append(idx[self._complete(self._make(idx)[1]).cpu()])
+            keep = torch.cat(keep) if keep else torch.zeros(0, dtype=torch.long)
+            if keep.numel() == 0:
+                raise RuntimeError('nyuv2: every one of the %d depth maps has sensor gaps (an exact 0 or 1)' % self.n)
+            self.rgb, self.depth = self.rgb[keep.to(device)], self.depth[keep.to(device)]
+            self.n = int(keep.numel())
         self.perm, self.i = torch.randperm(self.n, generator=self.gen), 0
-        self.max_retries = 16
 
     def _indices(self, k):
         out = []
@@ -65,19 +77,27 @@ class PairSource:
             y = y[bi, rows[:, :, None], cols[:, None, :]]
         return x / 255.0, y / 65535.0
 
+    @staticmethod
+    def _complete(y):
+        flat = y.reshape(y.shape[0], -1)
+        return ~((flat == 0).any(1) | (flat == 1).any(1))                     # hem/data/nyuv2.py:258-262
+
     def next_batch(self):
-        xs, ys, need, tries = [], [], self.B, 0
+        """Frames are redrawn until B crops pass the filter, however sparse the valid ones are (the reference's filter is
+        unbounded); the only failure is NO progress: `barren_passes` whole passes over the shard without a single valid crop."""
+        xs, ys, need, barren = [], [], self.B, 0
         while need > 0:
             x, y = self._make(self._indices(need))
-            flat = y.reshape(y.shape[0], -1)
-            ok = ~((flat == 0).any(1) | (flat == 1).any(1))                   # hem/data/nyuv2.py:258-262
-            tries += 1
-            if tries > self.max_retries:
-                raise RuntimeError('nyuv2: no depth crop without sensor gaps after %d draws' % self.max_retries)
+            ok = self._complete(y) if self.crop else torch.ones(y.shape[0], dtype=torch.bool, device=y.device)
             if ok.any():
                 xs.append(x[ok])
                 ys.append(y[ok])
                 need -= int(ok.sum())
+                barren = 0
+            else:
+                barren += int(y.shape[0])
+                if barren >= self.barren_passes * max(self.n, 1):
+                    raise RuntimeError('nyuv2: no depth crop without sensor gaps in %d passes over %d frames' % (self.barren_passes, self.n))
         return torch.cat(xs)[:self.B].contiguous(), torch.cat(ys)[:self.B].contiguous()
 
 
@@ -119,8 +139,7 @@ class NYUv2Dataset(DataPlugin):
             depth.append(d[..., 0].astype(np.uint16) if d.dtype != np.uint16 else d[..., 0])
         rgb, depth = np.stack(rgb), np.stack(depth)
         if cache:
-            os.makedirs(args.cache_dir, exist_ok=True)
-            np.savez(cache, rgb=rgb, depth=depth)
+            write_cache_atomically(cache, lambda f: np.savez(f, rgb=rgb, depth=depth))
         return rgb, depth
 
     @staticmethod

@@ -161,7 +161,7 @@ class CnnReplica(engine.GraphRunner):
 
     def losses(self):
         s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
-        return collection_to_dict([('tower_%d/loss/loss:0' % self.sess.rank, s[0])])
+        return collection_to_dict([('tower_%d/loss/loss:0' % (self.sess.world_size - 1), s[0])])
 
     def samples(self, n):
         """(inputs, outputs) as float32 NHWC in [-1, 1] (models/cnn.py:60-67)."""

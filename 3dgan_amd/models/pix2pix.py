@@ -301,7 +301,7 @@ class pix2pix(ModelPlugin, engine.GraphRunner):
         self._stage(batch)
         self._run('report', self._report_body)
         s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
-        r = self.sess.rank
+        r = self.sess.world_size - 1     # the dict keeps the LAST tower's tensors (util.py:187-193, App. C-11), as models/gan.py does
         g_total = s[self.S_GFAKE] + (L1_WEIGHT * s[self.S_L1] if self.args.add_l1 else 0.0)
         g_name = 'loss/generator/add:0' if self.args.add_l1 else 'loss/generator/g_fake:0'
         return collection_to_dict([('tower_%d/loss/generator/l1:0' % r, s[self.S_L1]), ('tower_%d/%s' % (r, g_name), g_total),

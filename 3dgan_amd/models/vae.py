@@ -199,7 +199,7 @@ class VaeReplica(engine.GraphRunner):
 
     def losses(self):
         s = self.sess.report_scalars(self.scal, mean=getattr(self.args, 'mean_loss', False)).cpu().tolist()
-        r = self.sess.rank
+        r = self.sess.world_size - 1     # the dict keeps the LAST tower's tensors (util.py:187-193, App. C-11), as models/gan.py does
         return collection_to_dict([('tower_%d/decoder_loss:0' % r, s[self.S_DLOSS]), ('tower_%d/latent_loss:0' % r, s[self.S_LLOSS]),
                                    ('tower_%d/total_loss:0' % r, s[self.S_DLOSS] + s[self.S_LLOSS])])
 

@@ -39,6 +39,7 @@ class Session:
         self._draws = 0
         self._draws_dev = torch.zeros(1, dtype=torch.int32, device=self.device)   # same count, device resident
         self.inject = {}                             # tests: {'z': [..], 'alpha': [..]} consumed in order
+        self.staged = {}                             # tests: {'z': device f32 tensor}, see stage_draws()
         self._flag = None
 
     # ---- RNG (tf.random_normal / tf.random_uniform, models/gan.py:246,224) ---------
@@ -53,6 +54,28 @@ class Session:
             return q.pop(0)
         return None
 
+    def stage_draws(self, key, values):
+        """Tests: from now on every draw of site `key` ('z', 'alpha', 'eps', ...) is a device-to-device copy out of ONE
+        fixed device buffer, which this call (re)fills from `values`.  Unlike `inject` (host arrays, eager steps only) the
+        copy is capturable, so hipGraph-captured step bodies replay with injected draws: refill before every optimizer step."""
+        t = torch.as_tensor(values, dtype=torch.float32).reshape(-1).to(self.device)
+        buf = self.staged.get(key)
+        if buf is None or buf.numel() != t.numel():
+            if buf is not None:
+                raise ValueError('staged draws of %r changed size (%d -> %d): the buffer address is captured' % (key, buf.numel(), t.numel()))
+            self.staged[key] = t.clone()
+        else:
+            buf.copy_(t)
+
+    def _staged_into(self, key, dst_flat, n):
+        buf = self.staged.get(key)
+        if buf is None:
+            return False
+        if buf.numel() < n:
+            raise ValueError('staged draws of %r hold %d values, the site draws %d' % (key, buf.numel(), n))
+        dst_flat[:n].copy_(buf[:n])
+        return True
+
     def random_normal(self, act, n_rows, key='z'):
         """Fill the first n_rows images of `act` with N(0,1) (per-replica stream)."""
         inj = self._injected(key)
@@ -60,6 +83,8 @@ class Session:
         if inj is not None:
             t = torch.as_tensor(inj, dtype=torch.float32).reshape(-1)
             act.buf[:n].copy_(t.to(self.device, K.TORCH_DTYPE[act.dtype]))
+            return
+        if self._staged_into(key, act.buf, n):
             return
         _lib.call('tdg_random_normal_dev', act.dtype, self.seed, (self.rank << 8) | 1, K.ptr(self._draws_dev), n,
                   act.ptr(0), K.stream())
@@ -69,6 +94,8 @@ class Session:
         inj = self._injected(key)
         if inj is not None:
             out[:n].copy_(torch.as_tensor(inj, dtype=torch.float32).reshape(-1).to(self.device))
+            return
+        if self._staged_into(key, out.view(-1), n):
             return
         _lib.call('tdg_random_uniform_f32_dev', self.seed, (self.rank << 8) | 2, K.ptr(self._draws_dev), n, K.ptr(out),
                   K.stream())

@@ -105,6 +105,30 @@ def cpu_baseline(args):
                       'torch-autograd port of the oracle, %d threads (CPU restatement, not TensorFlow)' % (n, B, dt, warm, cores)}
 
 
+def cpu_baseline_pix2pix(batch=8):
+    """Config 4's CPU figure: the oracle's torch-autograd port of hem/models/pix2pix.py (oracle/pix2pix_ref.py), one
+    train() call (D step + G step + loss fetch on 3 batches) at a stated batch, f32, on the host cores."""
+    from oracle import pix2pix_ref as PR, torch_ref as TR
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    a = SimpleNamespace(optimizer='adam', lr=1e-4, beta1=0.5, beta2=0.999, decay=0.9, momentum=0.01, n_disc_train=1,
+                        batch_norm_disc=False, batch_norm_gen=False, add_l1=False, noise=[], dropout=0)
+    tr = PR.Trainer(TR.to_torch(PR.init_params(a, 0, np.float32)), a)
+    g = torch.Generator().manual_seed(1234)
+    pair = lambda: (torch.rand(batch, 256, 256, 3, generator=g), torch.rand(batch, 256, 256, 1, generator=g) * 0.98 + 0.01)
+    tr.d_step(*pair())                              # untimed warm-up (allocator, thread pool)
+    t0 = time.time()
+    tr.train([pair() for _ in range(3)])
+    dt = time.time() - t0
+    return {'value': batch / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': 'one train() call (D step + G step + loss fetch, 3 batches) at batch %d in %.1f s after one warm-up D step, '
+                      'f32 torch-autograd port of the oracle, %d threads (CPU restatement, not TensorFlow)' % (batch, dt, cores)}
+
+
 def newest_pmc_file():
     """The committed PMC summary (profiles/rNN_*_pmc_fetch_write_per_kernel.json) of the newest build."""
     d = os.path.join(ROOT, 'profiles')
@@ -220,11 +244,12 @@ def secondary_leg(model, sess_dtype, K, rt, data, models, steps=5):
     rec = instrumented(train.replica, fn, K, 1)
     ips = B / dt
     tf = ips * GFLOP_PER_IMAGE[model] / 1e3
-    r = roofline_of(rec, 'bf16', 1, dt * 1e3, with_traffic=False)
+    r = roofline_of(rec, 'bf16', 1, dt * 1e3)
     out = {'workload': work, 'ms_per_call': dt * 1e3, 'images_per_sec': ips, 'dtype': 'bf16',
            'call_tflops': tf, 'call_frac_of_peak': tf / PEAK_TFLOPS['bf16'],
-           'dominant_kernel': {k: r[k] for k in ('kernel', 'achieved', 'frac', 'launches', 'avg_launch_ms', 'flop_per_launch')},
-           'all_conv_gemms': r['all_conv_gemms'],
+           'dominant_kernel': {k: r[k] for k in ('kernel', 'achieved', 'frac', 'launches', 'avg_launch_ms', 'flop_per_launch',
+                                                 'traffic', 'traffic_source')},
+           'all_conv_gemms': r['all_conv_gemms'], 'per_kernel': r['per_kernel'],
            'final_losses': {k: float(v) for k, v in (status or {}).items()}}
     del train, fn
     torch.cuda.empty_cache()
@@ -244,6 +269,8 @@ def main():
     ap.add_argument('--cpu_iters', type=int, default=3)
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--no_secondary', action='store_true', help='skip the pix2pix / vae / f32 legs of config.secondary')
+    ap.add_argument('--secondary_legs', default='pix2pix,vae,f32', help='which legs of config.secondary to run')
+    ap.add_argument('--no_headline_timer', action='store_true', help='profiling passes of the secondary legs: skip the instrumented headline steps')
     ap.add_argument('--no_kernel_timer', action='store_true')
     ap.add_argument('--timer_steps', type=int, default=2)
     ap.add_argument('--no_graphs', action='store_true')
@@ -296,7 +323,7 @@ def main():
     # are repeated eagerly, directly after the timed region, with every conv GEMM launch bracketed by events
     # on the launch stream (rank 0 only; the other ranks run the same steps so collectives stay matched).
     timer = None
-    if not args.no_kernel_timer and args.timer_steps > 0:
+    if not args.no_kernel_timer and not args.no_headline_timer and args.timer_steps > 0:
         rep.use_graphs = False
         rep.train_func()
         if sess.rank == 0:
@@ -350,9 +377,13 @@ def main():
             del rep
             torch.cuda.empty_cache()
             sec = {}
+            legs = args.secondary_legs.split(',')
             for m in ('pix2pix', 'vae'):
-                sec['%s_bs%d' % (m, 64 if m == 'pix2pix' else 512)] = secondary_leg(m, K.BF16, K, rt, data, models)
-            if args.dtype == 'bf16' and args.model == 'iwgan':
+                if m in legs:
+                    sec['%s_bs%d' % (m, 64 if m == 'pix2pix' else 512)] = secondary_leg(m, K.BF16, K, rt, data, models)
+            if 'pix2pix' in legs and not args.no_cpu_baseline:
+                sec['pix2pix_bs64']['cpu_baseline'] = cpu_baseline_pix2pix()
+            if args.dtype == 'bf16' and args.model == 'iwgan' and 'f32' in legs:
                 # the parity dtype on the headline workload: exact-f32 MFMA path
                 s32, r32 = headline_replica('f32')
                 d32, st32 = time_calls(r32.train_func, 3, 3)

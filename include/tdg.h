@@ -231,7 +231,8 @@ int tdg_cast_from_f32(int dtype, const float* in, size_t n, void* out, void* str
 /* xhat[r,:] = x[r,:] + alpha[r] * (g[r,:] - x[r,:])   (models/gan.py:225-226) */
 int tdg_gp_interp(int dtype, const void* x, const void* g, const float* alpha, int rows, int cols,
                   void* xhat, void* stream);
-/* acc[0] = beta*acc[0] + sum(x^2) over n elements (models/gan.py:229); deterministic */
+/* acc[0] = beta*acc[0] + sum(x^2) over n elements (models/gan.py:229); deterministic.
+ * ONE-STREAM RULE: the kernel hands its last block a ticket from a per-process device-global slot, so launches of this entry point must not overlap on the device; the library returns TDG_EINVAL if it is launched on a second (non-capturing) stream of the process. */
 int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* workspace,
               size_t workspace_bytes, void* stream);
 size_t tdg_reduce_workspace_bytes(size_t n);
@@ -304,7 +305,8 @@ int tdg_adam_step(float* p, const float* g, float* m, float* v, size_t n, float 
                   float beta2, float eps, float grad_scale, void* stream);
 /* Same update with the step count t kept in device memory (t_dev[0] = number of steps already applied):
  * lr_t is derived in-kernel, so a captured hipGraph can be replayed without re-baking arguments, and the kernel itself
- * counts the step (t_dev[0] += 1, by its last block). */
+ * counts the step (t_dev[0] += 1, by its last block).
+ * ONE-STREAM RULE: the kernel hands its last block a ticket from a per-process device-global slot, so launches of this entry point must not overlap on the device; the library returns TDG_EINVAL if it is launched on a second (non-capturing) stream of the process. */
 int tdg_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
                       float beta2, float eps, float grad_scale, int32_t* t_dev, void* stream);
 int tdg_add_i32(int32_t* x, int32_t inc, void* stream);
@@ -339,7 +341,8 @@ int tdg_random_normal(int dtype, uint64_t seed, uint64_t stream_id, uint64_t off
 int tdg_random_uniform_f32(uint64_t seed, uint64_t stream_id, uint64_t offset, size_t n, float* out,
                            void* stream);
 /* Graph-replayable forms: the counter offset is ((draw_dev[0] + 1) << 24), read from device memory, and the kernel
- * itself counts the draw (draw_dev[0] += 1, by its last block), so a replay of the same launch is a fresh draw. */
+ * itself counts the draw (draw_dev[0] += 1, by its last block), so a replay of the same launch is a fresh draw.
+ * ONE-STREAM RULE: the kernel hands its last block a ticket from a per-process device-global slot, so launches of this entry point must not overlap on the device; the library returns TDG_EINVAL if it is launched on a second (non-capturing) stream of the process. */
 int tdg_random_normal_dev(int dtype, uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n,
                           void* out, void* stream);
 int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, int32_t* draw_dev, size_t n, float* out,

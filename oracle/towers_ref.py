@@ -1,0 +1,123 @@
+"""CPU restatement of the reference's multi-tower training step: n independent replicas of the model graph on n
+different batch shards, the arithmetic mean of their gradients variable by variable, ONE optimizer step on the
+shared variables.
+
+TEST INFRASTRUCTURE ONLY (see oracle/tf_ops.py header).  PARITY UNPINNED against TensorFlow, like the single-tower
+oracles this file composes (oracle/gan_ref.py, vae_ref.py, pix2pix_ref.py).
+
+Follows (relative to /root/reference):
+  util.py:54-77        tower_scope_range: one tower per GPU, tower i gets rows [i*B, (i+1)*B) of the global batch
+                       (ops/input.py:11-25); variables are shared (reuse after tower 0)
+  models/gan.py:55-70  per tower: OWN z (:246) and alpha (:224) draws, own batch statistics, own whole-batch penalty norm
+  models/gan.py:65-68  per-tower compute_gradients for the two nets
+  util.py:118-147      average_gradients: mean over the tower axis
+  models/gan.py:76-81  one apply_gradients per net on the averaged gradients
+  util.py:187-193      the reported loss dict keeps the LAST tower's tensors
+  models/vae.py:31-47, hem/models/pix2pix.py:101-133: the same tower loop around their own losses
+
+This is what SURVEY section 4 names as the oracle of a multi-rank run: "n independent replicas, then mean" (batch
+norm and the penalty norm are per tower, so it is NOT one replica on the concatenated batch).
+"""
+import numpy as np
+
+from . import gan_ref as G
+from . import tf_ops as T
+
+
+class GanTowers:
+    """models/gan.py:39-91 with n towers.  Every step takes one (x, z, alpha) triple PER TOWER."""
+
+    def __init__(self, P, cfg, args):
+        self.P, self.cfg, self.args = P, cfg, args
+        self.g_opt, self.d_opt = T.init_optimizer(args), T.init_optimizer(args)     # models/gan.py:46
+        self.last_d_grads = self.last_g_grads = None
+
+    @staticmethod
+    def rescale(x01):
+        return 2.0 * (x01.reshape(x01.shape[0], -1) - 0.5)                           # models/gan.py:49-50
+
+    def d_step(self, xs, zs, alphas):
+        tower = [G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg)[1] for x, z, a in zip(xs, zs, alphas)]
+        self.last_d_grads = T.average_gradients(tower)                               # models/gan.py:77
+        self.d_opt.apply(self.P, self.last_d_grads)                                  # :81
+
+    def g_step(self, xs, zs, alphas):
+        """[g_train_op, losses] (models/gan.py:172): the losses are those of the LAST tower's batch, on the
+        variables before this step's update."""
+        tower, rep = [], None
+        for x, z, a in zip(xs, zs, alphas):
+            gl, gg, _ = G.g_loss_and_grads(self.P, z, self.cfg)
+            dl, _, _ = G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg, want_grads=False)
+            tower.append(gg)
+            rep = {'g_loss': float(gl), 'd_loss': float(dl)}
+        self.last_g_grads = T.average_gradients(tower)                               # :76
+        self.g_opt.apply(self.P, self.last_g_grads)                                  # :80
+        return rep
+
+    def gan_step(self, xs, zs):
+        """_train_gan (models/gan.py:110-131): one batch per tower, both nets updated from the same forward."""
+        dt, gt, rep = [], [], None
+        for x, z in zip(xs, zs):
+            gl, gg, _ = G.g_loss_and_grads(self.P, z, self.cfg)
+            dl, dg, _ = G.d_loss_and_grads(self.P, self.rescale(x), z, None, self.cfg)
+            dt.append(dg)
+            gt.append(gg)
+            rep = {'g_loss': float(gl), 'd_loss': float(dl)}
+        self.last_d_grads, self.last_g_grads = T.average_gradients(dt), T.average_gradients(gt)
+        self.d_opt.apply(self.P, self.last_d_grads)
+        self.g_opt.apply(self.P, self.last_g_grads)
+        return rep
+
+
+class VaeTowers:
+    """models/vae.py:25-51 with n towers (default_training: one optimizer step per call)."""
+
+    def __init__(self, P, args):
+        from . import vae_ref as V
+        self.V, self.P, self.opt = V, P, T.init_optimizer(args)
+        self.last_grads = None
+
+    def step(self, xs, epss):
+        tower, rep = [], None
+        for x, e in zip(xs, epss):
+            losses, c = self.V.forward(self.P, x, e)
+            tower.append(self.V.backward(self.P, c))
+            rep = {k: float(v) for k, v in losses.items()}
+        self.last_grads = T.average_gradients(tower)
+        self.opt.apply(self.P, self.last_grads)
+        return rep
+
+
+class Pix2pixTowers:
+    """hem/models/pix2pix.py:101-133,151-156 with n towers, on torch autograd (P: dict of float64 leaf tensors)."""
+
+    def __init__(self, P, args):
+        from . import pix2pix_ref as PR
+        from . import torch_ref as TR
+        self.PR, self.TR, self.P, self.args = PR, TR, P, args
+        self.g_opt, self.d_opt = TR.make_optimizer(args), TR.make_optimizer(args)
+        self.last_d_grads = self.last_g_grads = None
+
+    def _mean(self, tower):
+        return {k: sum(t[k] for t in tower) / len(tower) for k in tower[0]}
+
+    def d_step(self, pairs):
+        tower = []
+        for x01, y01 in pairs:
+            _, d_total, _ = self.PR.losses(self.P, x01, y01, self.args)
+            tower.append(self.TR.grads_of(d_total, self.P, 'discriminator/'))
+        self.last_d_grads = self._mean(tower)
+        self.d_opt.apply(self.P, self.last_d_grads)
+
+    def g_step(self, pairs):
+        tower = []
+        for x01, y01 in pairs:
+            g_total, _, _ = self.PR.losses(self.P, x01, y01, self.args)
+            tower.append(self.TR.grads_of(g_total, self.P, 'generator/'))
+        self.last_g_grads = self._mean(tower)
+        self.g_opt.apply(self.P, self.last_g_grads)
+
+    def report(self, pairs):
+        import torch
+        with torch.no_grad():
+            return self.PR.losses(self.P, *pairs[-1], self.args)[2]                  # the last tower's batch

@@ -1,7 +1,16 @@
 """The N > 1 path on the one-GPU box: two replica processes (torch.distributed.run, gloo standing in for RCCL, both on
 cuda:0) stepping the iwgan schedule with the split D-gradient bodies and the early all-reduce of the largest filter's
-slice.  With identical data and RNG keys in both replicas the tower mean equals each tower's gradient, so losses and
-every variable must equal the single-replica run bit for bit."""
+slice.
+
+Three kinds of rehearsal (tests/_dist_worker.py):
+* identical data and RNG keys in both replicas: the tower mean equals each tower's gradient, so losses and every
+  variable must equal the single-replica run bit for bit (catches a wrong 1/n);
+* DIFFERENT shards and RNG keys per replica (the reference's towers, util.py:54-77 + ops/input.py:11-25): the
+  two-process run must equal, bit for bit, the same two towers run one after the other in ONE process with their
+  buckets added by hand (bf16, hipGraphs, on-device Philox) -- and, on the f32 path with staged draws, the float64
+  oracle's "n independent replicas, then the mean, then one optimizer step" (oracle/towers_ref.py, util.py:118-147)
+  within the north-star's 1e-3.  A dropped slice exchange is an O(1) error here;
+* the same comparisons with an exchange deliberately dropped (TDG_TEST_SABOTAGE) must FAIL."""
 import os
 import subprocess
 import sys
@@ -11,17 +20,172 @@ import pytest
 
 from conftest import ROOT
 
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import _tower_inputs as TI                                   # noqa: E402
+
 pytestmark = pytest.mark.gpu
+
+WORKER = os.path.join(ROOT, 'tests', '_dist_worker.py')
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                              'TDG_TEST_SABOTAGE')}
+    env.update(TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', **extra)
+    return env
+
+
+def _two_ranks(out, model, mode, port, **extra):
+    subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+                    '127.0.0.1', '--master-port', str(port), WORKER, out, model, mode], check=True, env=_env(**extra), timeout=900)
+    return np.load(out)
+
+
+def _mismatches(a, b):
+    assert set(a.files) == set(b.files)
+    return [k for k in a.files if not np.array_equal(a[k], b[k])]
+
+
+@pytest.mark.parametrize('model,port', [('iwgan', 29561), ('wgan', 29562), ('vae', 29563), ('pix2pix', 29564)])
+def test_two_replicas_on_different_shards_equal_the_tower_mean(tmp_path, model, port):
+    """bf16, hipGraphs on, rank-keyed Philox draws, own shard per replica: 4 training iterations of the two-process run
+    (split critic exchange, asynchronous generator bucket) == the two towers stepped in one process with their gradient
+    buckets added by hand, bit for bit (variables and the last tower's reported losses)."""
+    towers = str(tmp_path / 'towers.npz')
+    subprocess.run([sys.executable, WORKER, towers, model, 'towers'], check=True, env=_env(), timeout=900)
+    a, b = np.load(towers), _two_ranks(str(tmp_path / 'two.npz'), model, 'shards', port)
+    for k in a.files:
+        assert np.all(np.isfinite(a[k])), k
+    assert _mismatches(a, b) == []
+
+
+@pytest.mark.parametrize('model,port,sabotage', [('iwgan', 29565, 'rest'), ('iwgan', 29566, 'g_async'), ('vae', 29567, 'bucket')])
+def test_a_dropped_exchange_is_detected(tmp_path, model, port, sabotage):
+    """The rehearsal above can fail: with the exchange of the critic bucket's remainder (`rest`), of the generator's
+    asynchronous bucket (`g_async`) or of a whole bucket (`bucket`) skipped, variables differ from the tower mean."""
+    towers = str(tmp_path / 'towers.npz')
+    subprocess.run([sys.executable, WORKER, towers, model, 'towers'], check=True, env=_env(), timeout=900)
+    a, b = np.load(towers), _two_ranks(str(tmp_path / 'two.npz'), model, 'shards', port, TDG_TEST_SABOTAGE=sabotage)
+    bad = _mismatches(a, b)
+    want = {'rest': 'discriminator.vars.c1.weights', 'g_async': 'generator.vars.dc1.weights', 'bucket': 'encoder.vars.c1.weights'}[sabotage]
+    assert want in bad, bad
+    print('sabotage %s detected in %d of %d arrays, e.g. %s' % (sabotage, len(bad), len(a.files), bad[:4]))
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def _rel_l2(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()) / (np.linalg.norm(np.asarray(b, np.float64).ravel()) + 1e-30))
+
+
+def _oracle_towers(model, init, world=2):
+    """The float64 oracle of the staged run: returns (final variables, last mean gradients by name, losses per iteration)."""
+    from oracle import towers_ref as TW
+    args = TI.make_args(model, world)
+    P = {k: np.asarray(v, np.float64) for k, v in init.items()}
+    step = [0]
+
+    def take(keys):
+        out = [TI.step_inputs(model, r, step[0]) for r in range(world)]
+        step[0] += 1
+        return [[np.asarray(o[k], np.float64) for o in out] for k in keys]
+    losses, grads = [], {}
+    if model == 'vae':
+        tw = TW.VaeTowers(P, args)
+        for _ in range(TI.ITERATIONS):
+            xs, es = take(['x', 'eps'])
+            losses.append(tw.step(xs, es))
+        grads = tw.last_grads
+        return tw.P, grads, losses
+    if model == 'pix2pix':
+        import torch
+        from oracle import torch_ref as TR
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        tw = TW.Pix2pixTowers(TR.to_torch(P, torch.float64), args)
+        as_pairs = lambda xy: [(torch.tensor(x), torch.tensor(y)) for x, y in zip(*xy)]
+        for _ in range(TI.ITERATIONS):
+            tw.d_step(as_pairs(take(['x', 'y'])))
+            tw.g_step(as_pairs(take(['x', 'y'])))
+            losses.append(tw.report(as_pairs(take(['x', 'y']))))
+        grads = {k: v.detach().numpy() for k, v in {**tw.last_d_grads, **tw.last_g_grads}.items()}
+        return {k: v.detach().numpy() for k, v in tw.P.items()}, grads, losses
+    from oracle import gan_ref as G
+    s = TI.SIZES[model]
+    cfg = G.make_cfg(model, s['shape'], s['L'], s['B'])
+    tw = TW.GanTowers(P, cfg, args)
+    for _ in range(TI.ITERATIONS):
+        for _d in range(TI.N_DISC):
+            tw.d_step(*take(['x', 'z', 'alpha']))
+        losses.append(tw.g_step(*take(['x', 'z', 'alpha'])))
+    grads = {**tw.last_d_grads, **tw.last_g_grads}
+    return tw.P, grads, losses
+
+
+@pytest.mark.parametrize('model,port', [('iwgan', 29571), ('wgan', 29572), ('vae', 29573), ('pix2pix', 29574)])
+def test_two_replicas_match_the_oracle_tower_mean_f32(tmp_path, model, port):
+    """f32 path, draws staged on the device (hipGraphs stay on), own shard and own z / alpha / eps per replica: after 3
+    training iterations rank 0's mean gradients, reported losses and the variables' total update equal the float64 oracle's
+    two independent replicas -> mean -> one optimizer step (oracle/towers_ref.py; util.py:118-147)."""
+    out = _two_ranks(str(tmp_path / 'staged.npz'), model, 'staged', port)
+    init = {k[5:].replace('.', '/'): out[k] for k in out.files if k.startswith('init.')}
+    name = lambda k: k.replace('.', '/')
+    P, grads, losses = _oracle_towers(model, init)
+    # reported losses: the LAST tower's (util.py:187-193), every iteration
+    lim = 1e-3
+    for k in losses[0]:
+        got = out['loss_' + k]
+        for it in range(TI.ITERATIONS):
+            ref = losses[it][k]
+            assert abs(got[it] - ref) <= lim * max(1.0, abs(ref)), (k, it, got[it], ref)
+    # mean gradients of the last critic / generator step (the all-reduced bucket / n)
+    worst = {}
+    for k in out.files:
+        if not k.startswith('grad.'):
+            continue
+        n = name(k[5:])
+        if n not in grads:
+            continue
+        if _zero_gradient_variable(model, n):
+            continue
+        worst[n] = _rel(out[k], grads[n])
+    assert worst and max(worst.values()) < lim, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    # the variables' total update over the run, where the gradient is significant (Adam / RMSProp normalise rounding noise
+    # of numerically-zero gradients to +-lr: tests/test_gpu_gan_step.py::relerr_where_significant)
+    upd = {}
+    for n, g in grads.items():
+        if _zero_gradient_variable(model, n):
+            continue
+        m = np.abs(g) > 1e-2 * np.abs(g).max()
+        d_hip = (out[n.replace('/', '.')].astype(np.float64) - init[n])[m]
+        d_ref = (P[n] - init[n].astype(np.float64))[m]
+        upd[n] = _rel_l2(d_hip, d_ref)
+    assert max(upd.values()) < 2e-2, sorted(upd.items(), key=lambda kv: -kv[1])[:5]
+
+
+def _zero_gradient_variable(model, n):
+    """Biases feeding a batch norm have an exactly-zero gradient in real arithmetic (rounding residue only)."""
+    if not n.endswith('/bias'):
+        return False
+    if model == 'wgan':
+        return ('/c2/' in n or '/c3/' in n) or (n.startswith('generator/') and 'dc4' not in n)
+    if model == 'iwgan':
+        return n.startswith('generator/') and 'dc4' not in n
+    if model == 'vae':
+        return n.startswith('encoder/')
+    if model == 'pix2pix':
+        return n.startswith('generator/decoder/')          # every decoder layer is batch-normalised (App. C-10)
+    return False
 
 
 @pytest.mark.parametrize('model,port', [('iwgan', 29533), ('wgan', 29534), ('vae', 29535), ('pix2pix', 29536)])
 def test_two_replicas_match_one(tmp_path, model, port):
     """iwgan: the headline schedule; wgan: config 3's model (rmsprop, one exchange per step); vae: config 5's model; pix2pix: config 4's
     (256 x 256, one pair per replica)."""
-    worker = os.path.join(ROOT, 'tests', '_dist_worker.py')
-    env = dict(os.environ, TDG_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    worker = WORKER
     one, two = str(tmp_path / 'one.npz'), str(tmp_path / 'two.npz')
-    env1 = {k: v for k, v in env.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env1 = _env()
     subprocess.run([sys.executable, worker, one, model], check=True, env=env1, timeout=600)
     subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
                     '127.0.0.1', '--master-port', str(port), worker, two, model], check=True, env=env1, timeout=600)

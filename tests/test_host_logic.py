@@ -95,6 +95,11 @@ def test_cli_defaults_alias_and_config_file(tmp_path):
     a = train.resolve_defaults(p.parse_args([]))
     assert train.resolve_defaults(p.parse_args(['--model', 'pix2pix'])).n_disc_train == 1
     assert train.resolve_defaults(p.parse_args(['--model', 'pix2pix', '--n_disc_train', '3'])).n_disc_train == 3
+    # ... and through the REAL three-pass parse (the plugin re-declares --n_disc_train with its own default of 1,
+    # hem/models/pix2pix.py:65-68; an earlier pass must not leave a None that hides it, nor may the gen-1 fallback of 5 win)
+    assert train.parse_args(['--model', 'pix2pix', '--dataset', 'synthetic']).n_disc_train == 1
+    assert train.parse_args(['--model', 'pix2pix', '--dataset', 'synthetic', '--n_disc_train', '3']).n_disc_train == 3
+    assert train.parse_args(['--model', 'iwgan', '--dataset', 'synthetic']).n_disc_train == 5
     # train.py:62-182 defaults
     assert (a.n_gpus, a.batch_size, a.n_disc_train, a.optimizer, a.lr, a.momentum, a.decay) == (1, 256, 5, 'rmsprop', 0.001, 0.01, 0.9)
     assert (a.beta1, a.beta2, a.latent_size, a.dataset, a.epochs, a.buffer_size) == (0.9, 0.999, 200, 'floorplans', '3', 10000)
