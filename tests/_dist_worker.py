@@ -194,20 +194,29 @@ def run(out_path, world, model='iwgan', mode='same'):
                 sess.stage_draws(k, inp[k])
             x = torch.tensor(inp['x'], device=dev)
             return (x, torch.tensor(inp['y'], device=dev)) if model == 'pix2pix' else x
-        for _ in range(TI.ITERATIONS):
+        def snap(store):                                               # the all-reduced bucket holds the SUM over replicas
+            if rank == 0:
+                i = len([k for k in extra if k.startswith('nstep.')])
+                extra['nstep.%d' % i] = np.zeros(0)
+                extra.update({'grad.%d.%s' % (i, k.replace('/', '.')): v.detach().cpu().numpy() / world for k, v in store.grad_views.items()})
+        for _ in range(TI.iterations(model)):
             if model == 'vae':
                 rep.step(feed(['eps']))
+                snap(rep.store)
                 losses.append(rep.losses())
             elif model == 'pix2pix':
                 rep.d_step(feed([]))
+                snap(rep.d_store)
                 rep.g_step(feed([]))
+                snap(rep.g_store)
                 losses.append(rep.report(feed([])))
             else:
                 for _d in range(rep.args.n_disc_train):
                     rep.d_step(feed(['z', 'alpha']))
+                    snap(rep.d_store)
                 rep.g_step(feed(['z', 'alpha']))
+                snap(rep.g_store)
                 losses.append(rep.losses())
-        extra.update({'grad.' + k.replace('/', '.'): v / world for k, v in rep.gradients().items()})   # buckets hold the SUM
     else:
         losses = [rep.train_func() for _ in range(TI.ITERATIONS + 1)]          # eager, capture, 2 replays
     torch.cuda.synchronize()

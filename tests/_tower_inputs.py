@@ -16,8 +16,8 @@ def make_args(model, world, use_graphs=True):
     s = SIZES[model]
     if model == 'vae':
         return SimpleNamespace(model='vae', batch_size=s['B'], latent_size=s['L'], image_shape=s['shape'], n_gpus=world,
-                               optimizer='adam', lr=1e-3, beta1=0.9, beta2=0.999, decay=0.9, momentum=0.01, centered=False,
-                               use_graphs=use_graphs)
+                               optimizer='rmsprop', lr=1e-3, beta1=0.9, beta2=0.999, decay=0.9, momentum=0.01, centered=False,
+                               use_graphs=use_graphs)              # config 5: train.py's optimizer defaults (train.py:113-136)
     if model == 'pix2pix':
         return SimpleNamespace(model='pix2pix', batch_size=s['B'], n_gpus=world, optimizer='adam', lr=1e-4, beta1=0.5,
                                beta2=0.999, decay=0.9, momentum=0.01, centered=False, n_disc_train=1, skip_layers=True,
@@ -28,6 +28,12 @@ def make_args(model, world, use_graphs=True):
     return SimpleNamespace(model=model, batch_size=s['B'], latent_size=s['L'], image_shape=s['shape'], n_gpus=world,
                            decay=0.9, momentum=0.01, centered=False, n_disc_train=N_DISC, display_d_loss=True,
                            use_graphs=use_graphs, **opt)
+
+
+def iterations(model):
+    """Staged (oracle) runs: pix2pix stops after the capture iteration (its replays are covered bit for bit by the
+    shards-vs-towers rehearsal; every further iteration is 220 MB of generator gradients to carry)."""
+    return 2 if model == 'pix2pix' else ITERATIONS
 
 
 def steps_per_iteration(model):
