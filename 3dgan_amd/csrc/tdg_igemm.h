@@ -19,9 +19,15 @@ struct IgClass {
   int oh0, ow0;
   unsigned w_off_bytes;  // this class's packed filter block inside the packed buffer
   FastDiv fd_ghw, fd_gw, fd_nw;
+  FastDiv fd_nt;         // divide by ntaps (K order of a sliced filter: see IgArgs.fd_ck)
   // taps form a grid: tap t = th*nw + tw reads source offset (dh0 + sh*th, dw0 + sw*tw)
   int nh, nw, dh0, dw0, sh, sw;
   short tap[IG_MAX_TAPS];  // (dh & 0xff) | ((dw & 0xff) << 8), signed bytes
+  // igemm_fwd_patch_kernel: the taps fall into <= 4 groups of consecutive taps that read one sub-lattice (ph, pw) of the
+  // source (stride-2 forward: the four pixel parities; stride-1 gathers: one group); tap t of group g reads lattice pixel
+  // (a + dhq, b + dwq) of a [QH, QW] lattice per image, dhq = (dh - ph) / sigma
+  int ngroups, QH, QW;
+  struct { short t0, nt, ph, pw; } grp[4];
 };
 
 struct IgArgs {
@@ -34,6 +40,12 @@ struct IgArgs {
   int SH, SW, sigma;
   int C, Cs;             // channels per tap in K (effective, multiple of VEC on the vector path), channel stride
   FastDiv fd_c;          // divide by C (scalar path) or by C/VEC (vector path)
+  // K order of the packed filter on the vector path: K chunk (16 bytes) index = (slice * ntaps + tap) * ckv + j with
+  // ckv = fd_ck.d chunks of a tap's channels per slice, channel vector cv = slice * ckv + j.  nslices = 1 (ckv = C/VEC)
+  // is the plain (tap, channel) order; a sliced filter (tdg_k_slice_chunks) lets igemm_fwd_patch_kernel keep a
+  // channel slice of the gathered operand resident in LDS across all the taps that read it.
+  FastDiv fd_ck;
+  int nslices;
   int N, OH, OW, os, Cso;
   int act, mask_mode, accumulate;
   float leak;

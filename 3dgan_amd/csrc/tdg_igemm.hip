@@ -89,6 +89,20 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) {
   return row * IG_BKB + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// K chunk (16 bytes of a packed filter row) -> (tap index in the class's tap table, channel vector of the tap), for the
+// plain (tap, channel) order and the sliced order of IgArgs.fd_ck alike: chunk = (slice * ntaps + tap) * ckv + j.
+struct KChunk { int tap, cv; bool ok; };
+__device__ __forceinline__ KChunk k_decode(unsigned chunk, const FastDiv& fd_ck, const FastDiv& fd_nt, int nslices) {
+  const unsigned u = fd_div(chunk, fd_ck);
+  const unsigned j = chunk - u * fd_ck.d;
+  const unsigned sl = fd_div(u, fd_nt);
+  KChunk r;
+  r.tap = (int)(u - sl * fd_nt.d);
+  r.cv = (int)(sl * fd_ck.d + j);
+  r.ok = (int)sl < nslices;
+  return r;
+}
+
 // ============================================================================================
 // forward-type implicit GEMM: conv2d fwd, conv2d bwd-data (parity classes), dense
 // ============================================================================================
@@ -148,31 +162,22 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
   }
   // k decomposition of this thread's chunk column: kv = step*8 + ch -> (tap, cvec)
   const int CV = (int)args.fd_c.d;  // vectors per tap (vector path) / channels per tap (scalar path)
-  int k_tap = 0, k_cv = 0;
-  if constexpr (VECA) {
-    k_tap = (int)fd_div((unsigned)ch, args.fd_c);
-    k_cv = ch - k_tap * CV;
-  }
 
   i32x4 ra[NA], rb[NB];
 
   auto load_tiles = [&](int step) {
     if constexpr (VECA) {
-      const bool t_ok = k_tap < ntaps;
-      const int pk = sTap[t_ok ? k_tap : 0];
+      const KChunk kc = k_decode((unsigned)(step * 8 + ch), args.fd_ck, cl.fd_nt, args.nslices);
+      const bool t_ok = kc.ok;
+      const int pk = sTap[t_ok ? kc.tap : 0];
       const int dh = tap_dh(pk), dw = tap_dw(pk);
-      const int koff = (dh * SW + dw) * Cs + k_cv * VEC;
+      const int koff = (dh * SW + dw) * Cs + kc.cv * VEC;
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int ih = a_h[i] + dh, iw = a_w[i] + dw;
         const bool ok = t_ok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
         const unsigned off = ok ? (a_base[i] + (unsigned)koff) * (unsigned)sizeof(T) : OOB_OFFSET;
         ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rA, off, 0, 0);
-      }
-      k_cv += 8;
-      while (k_cv >= CV) {
-        k_cv -= CV;
-        ++k_tap;
       }
     }
 #pragma unroll
@@ -341,31 +346,6 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
   }
 }
 
-// Per-lane walk over the K dimension of the vector gather: K chunk index -> (tap row, tap column,
-// 16-byte vector inside the tap's channels), advanced incrementally (no division, no table lookup,
-// no divergent loop on the common path).
-struct TapWalk {
-  int cv, th, tw;
-  __device__ __forceinline__ void init(int chunk, const FastDiv& fd_cv, int nw) {
-    const int t = (int)fd_div((unsigned)chunk, fd_cv);
-    cv = chunk - t * (int)fd_cv.d;
-    th = t / nw;
-    tw = t - th * nw;
-  }
-  __device__ __forceinline__ void advance(int inc, int CV, int nw) {
-    const int sub = CV >= inc ? inc : 1;            // wave-uniform: one wrap at most per sub-step
-    for (int r = 0; r < inc; r += sub) {
-      cv += sub;
-      const int wrap = cv >= CV;
-      cv -= wrap ? CV : 0;
-      tw += wrap;
-      const int wrap2 = tw >= nw;
-      tw = wrap2 ? 0 : tw;
-      th += wrap2;
-    }
-  }
-};
-
 // ============================================================================================
 // Large-M variant of the forward-type GEMM: 256 x BN tile, 8 waves (one 32-row strip each),
 // operands streamed by LDS-DMA (`buffer_load_dwordx4 ... lds`, no VGPR staging, no ds_write) into a
@@ -397,7 +377,8 @@ struct DmaLoader {
   int a_lds[NAJ], b_lds[NBJ];   // wave-uniform byte offsets inside a stage
   int SH, SW, Cs, CV, ntaps, lch;
   int tapreg;                   // the class's tap table, entry (lane & 31) in each lane
-  FastDiv fd_cv;
+  FastDiv fd_ck, fd_nt;         // K order of the packed filter (IgArgs.fd_ck)
+  int nslices;
   // state of the step being loaded
   int dh, dw, t_ok;
   unsigned koff, kbyte;
@@ -408,11 +389,10 @@ struct DmaLoader {
   //  filter, which the host is free to choose -- see fwd_tap_order)
   __device__ __forceinline__ void prepare(int step) {
     step += step0;
-    const unsigned chunk = (unsigned)(step * 8 + lch);
-    const unsigned t = fd_div(chunk, fd_cv);
-    const int cv = (int)(chunk - t * (unsigned)CV);
-    t_ok = (int)t < ntaps;
-    const int pk = __builtin_amdgcn_ds_bpermute((int)(t_ok ? t : 0u) << 2, tapreg);   // lane i holds tap i: a lane crossbar
+    const KChunk kc = k_decode((unsigned)(step * 8 + lch), fd_ck, fd_nt, nslices);
+    const int cv = kc.cv;
+    t_ok = kc.ok;
+    const int pk = __builtin_amdgcn_ds_bpermute((t_ok ? kc.tap : 0) << 2, tapreg);    // lane i holds tap i: a lane crossbar
     dh = tap_dh(pk);                                                                  // read, not an LDS access the
     dw = tap_dw(pk);                                                                  // compiler would fence the DMA for
     koff = (unsigned)((dh * SW + dw) * Cs + cv * VEC);                                // (requesting the entry a step ahead
@@ -436,6 +416,13 @@ struct DmaLoader {
     if constexpr (P < NP) {
       piece<P>(stage);
       all_pieces<P + 1>(stage);
+    }
+  }
+  template <int P = NAJ>
+  __device__ __forceinline__ void b_pieces(char* stage) const {      // diagnostics (TDG_DEBUG_ABLATE=7): the filter pieces only
+    if constexpr (P < NP) {
+      piece<P>(stage);
+      b_pieces<P + 1>(stage);
     }
   }
 };
@@ -562,7 +549,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
   ld.rB = make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, (dbg == 5 || dbg == 6) ? 0u : args.w_bytes - cl.w_off_bytes);
   ld.SH = args.SH; ld.SW = args.SW; ld.Cs = args.Cs; ld.CV = (int)args.fd_c.d;
   ld.ntaps = cl.ntaps; ld.tapreg = cl.tap[lane & (IG_MAX_TAPS - 1)];
-  ld.fd_cv = args.fd_c;
+  ld.fd_ck = args.fd_ck; ld.fd_nt = cl.fd_nt; ld.nslices = args.nslices;
   ld.lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);   // this lane's logical K chunk
 
   // ---- A rows served by this lane: LDS rows 8*I_j + rsub, I_j = 2*(NAJ*wh + j) + par ------------------
@@ -689,6 +676,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
       // two separate loops with the same barrier sequence: the loader state is dead in the compute loop (one merged
       // loop kept it live beside the accumulators and the fragments: spills)
       if (is_loader) {
+        for (; dbg == 7 && step < nsteps - 2; ++step) {   // diagnostics: what the loop costs WITHOUT the gathered operand's pieces
+          const int nxt2 = cur == 0 ? 2 : cur - 1;       // (results are garbage: the A rows of the ring are never refreshed)
+          ld.prepare(step + 2);
+          ld.b_pieces(smem + nxt2 * STAGE);
+          static_assert(LD::NBJ == 7 || LD::NBJ == 4 || LD::NBJ == 8 || LD::NBJ == 2 || LD::NBJ == 1, "add the immediate");
+          if constexpr (LD::NBJ == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          cur = cur == 2 ? 0 : cur + 1;
+        }
         for (; step < nsteps - 2; ++step) {
           const int nxt2 = cur == 0 ? 2 : cur - 1;     // (cur + 2) % 3
           TDG_STAMP(t0);
@@ -1775,6 +1773,7 @@ struct PackArgs {
   const float* w;
   void* out;
   int rows, ntaps, C, Ceff, Kp;
+  int CK;                // channels of a tap per K slice (= Ceff: plain (tap, channel) order; IgArgs.fd_ck otherwise)
   int stride_tap, stride_row, stride_ch;
   unsigned char tap_ids[IG_MAX_TAPS];
 };
@@ -1794,7 +1793,8 @@ __device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by, flo
       const int i = ty + 8 * p, r = r0 + tx, k = k0 + i;
       float v = 0.f;
       if (r < a.rows && k < kmax) {
-        const int ti = k / a.Ceff, c = k - ti * a.Ceff;
+        const int sl = k / (a.ntaps * a.CK), kr = k - sl * (a.ntaps * a.CK);
+        const int ti = kr / a.CK, c = sl * a.CK + (kr - ti * a.CK);
         if (c < a.C) v = a.w[(size_t)a.tap_ids[ti] * a.stride_tap + (size_t)r * a.stride_row + (size_t)c * a.stride_ch];
       }
       tile[i][tx] = v;                                      // tile[k_local][r_local]
@@ -1804,7 +1804,8 @@ __device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by, flo
     for (int h = 0; h < PACK_TK / 32; ++h) {
       const int kl = h * 32 + tx, k = k0 + kl;
       const bool kok = k < kmax;
-      const int ti = kok ? k / a.Ceff : 0, c = k - ti * a.Ceff;
+      const int sl = kok ? k / (a.ntaps * a.CK) : 0, kr = k - sl * (a.ntaps * a.CK);
+      const int ti = kok ? kr / a.CK : 0, c = sl * a.CK + (kr - ti * a.CK);
       const size_t base = (size_t)a.tap_ids[ti] * a.stride_tap + (size_t)c * a.stride_ch;
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
@@ -2680,6 +2681,16 @@ inline int eff_channels(int c, int cs, int vec) {
   return (cs % vec == 0 && ce <= cs) ? ce : 0;
 }
 
+// K order of a packed filter on the bf16 vector path: chunks (16 bytes = 8 channels) of a tap's channels per K slice.
+// 5-chunk slices (C / 8 a multiple of 5: the GAN's 200 / 400 / 800 channels) are what igemm_fwd_patch_kernel keeps resident in
+// LDS -- 80-byte pixels, an odd number of 16-byte chunks, so its fragment reads spread over all banks; every other
+// forward-type kernel reads the sliced order through k_decode.  cv: chunks per tap.  Returns cv for the plain order.
+inline int k_slice_chunks(int dtype, int cv) {
+  static const int enabled = getenv("TDG_KSLICE") ? atoi(getenv("TDG_KSLICE")) : 1;   // diagnostics: 0 = plain order everywhere
+  if (!enabled || dtype != TDG_BF16 || cv < 5 || cv % 5 != 0) return cv;
+  return 5;
+}
+
 // K order of the forward filter's taps.  Stride 2: the taps of one (kh & 1, kw & 1) parity class read the same quarter
 // of the input pixels (shifted by whole output pixels) and no other class touches that quarter, so walking K class by
 // class keeps a workgroup's live input at 1/4 of its slab for 4-9 consecutive taps: with 32 workgroups per XCD that
@@ -2939,6 +2950,7 @@ static void build_pack_fwd(const TdgConvDesc* d, const float* w, void* packed, P
   a->ntaps = d->kh * d->kw;
   a->C = d->c;
   a->Ceff = ce;
+  a->CK = (ce % vec == 0 && eff_channels(d->c, d->cs, vec)) ? k_slice_chunks(d->dtype, ce / vec) * vec : ce;
   a->Kp = (int)tdg_round_up((long long)a->ntaps * ce, bke);
   a->stride_tap = d->c * d->k;
   a->stride_row = 1;       // row = small-side channel (last master index)
@@ -2966,6 +2978,7 @@ static int build_pack_bwd(const TdgConvDesc* d, const float* w, void* packed, Pa
     a.ntaps = cls[i].ntaps;
     a.C = d->k;
     a.Ceff = ke;
+    a.CK = (ke % vec == 0 && eff_channels(d->k, d->ks, vec)) ? k_slice_chunks(d->dtype, ke / vec) * vec : ke;
     a.Kp = (int)tdg_round_up((long long)a.ntaps * ke, bke);
     a.stride_tap = d->c * d->k;
     a.stride_row = d->k;    // row = big-side channel
@@ -2984,6 +2997,7 @@ static void build_pack_col2im(const TdgConvDesc* d, const Col2imPlan& cp, const 
   a->ntaps = 1;
   a->C = d->k;
   a->Ceff = cp.ke;
+  a->CK = cp.ke;
   a->Kp = cp.KP;
   a->stride_tap = 0;
   a->stride_row = d->k;
@@ -3202,7 +3216,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
     return TDG_OK;
   }
   static const int n1_enabled = getenv("TDG_CONVN1") ? atoi(getenv("TDG_CONVN1")) : 1;   // diagnostics: 0 = the 128 x 16 MFMA tile
-  if (n1_enabled && d->k == 1 && veca && d->kh * d->kw <= IG_MAX_TAPS && (long long)n_images * d->oh * d->ow >= 1024 &&
+  if (n1_enabled && d->k == 1 && veca && k_slice_chunks(d->dtype, C / vec) == C / vec && d->kh * d->kw <= IG_MAX_TAPS && (long long)n_images * d->oh * d->ow >= 1024 &&
       !(epi && (epi->accumulate || epi->mask_mode != TDG_MASK_NONE))) {
     if (epi && epi->col_nblk_out) *epi->col_nblk_out = 0;       // no column partials from this kernel: the host runs its own pass
     ConvN1Args f;
@@ -3243,6 +3257,8 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   a.SH = d->h; a.SW = d->w; a.sigma = d->stride;
   a.C = C; a.Cs = d->cs;
   a.fd_c = make_fastdiv(veca ? C / vec : C);
+  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec) : C);
+  a.nslices = (int)(a.fd_c.d / a.fd_ck.d);
   a.N = d->k; a.OH = d->oh; a.OW = d->ow; a.os = 1; a.Cso = d->ks;
   a.nclasses = 1;
   IgClass& c = a.cls[0];
@@ -3261,6 +3277,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(ord[t] / d->kw - d->pad_t, ord[t] % d->kw - d->pad_l);
   c.nh = d->kh; c.nw = d->kw; c.dh0 = -d->pad_t; c.dw0 = -d->pad_l; c.sh = c.sw = 1;
   c.fd_nw = make_fastdiv(c.nw);
+  c.fd_nt = make_fastdiv(c.ntaps);
   const int bn = pick_bn(d->k);
   t_flops = conv_flops(d, n_images);
   return d->dtype == TDG_BF16 ? launch_fwd<bf16_t>(a, veca, bn, (hipStream_t)stream)
@@ -3366,6 +3383,8 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
   a.SH = d->oh; a.SW = d->ow; a.sigma = 1;
   a.C = C; a.Cs = d->ks;
   a.fd_c = make_fastdiv(veca ? C / vec : C);
+  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec) : C);
+  a.nslices = (int)(a.fd_c.d / a.fd_ck.d);
   a.N = d->c; a.OH = d->h; a.OW = d->w; a.os = d->stride; a.Cso = d->cs;
   BwdClassPlan plan[IG_MAX_CLASSES];
   const int nc = plan_bwd_classes(d, plan);
@@ -3393,6 +3412,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     for (int t = 0; t < c.ntaps; ++t) c.tap[t] = pack_tap(plan[i].dh[t], plan[i].dw[t]);
     c.nh = plan[i].nh; c.nw = plan[i].nw; c.dh0 = plan[i].dh[0]; c.dw0 = plan[i].dw[0]; c.sh = c.sw = -1;
     c.fd_nw = make_fastdiv(c.nw);
+    c.fd_nt = make_fastdiv(c.ntaps);
     off += (unsigned)((size_t)d->c * Kp * es);
   }
   const int bn = pick_bn(d->c);
