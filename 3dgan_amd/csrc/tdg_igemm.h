@@ -27,6 +27,7 @@ struct IgClass {
   // source (stride-2 forward: the four pixel parities; stride-1 gathers: one group); tap t of group g reads lattice pixel
   // (a + dhq, b + dwq) of a [QH, QW] lattice per image, dhq = (dh - ph) / sigma
   int ngroups, QH, QW;
+  FastDiv fd_qhw, fd_qw;   // divide by QH * QW, by QW
   struct { short t0, nt, ph, pw; } grp[4];
 };
 

@@ -975,6 +975,432 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
   }
 }
 
+// ============================================================================================
+// Patch-resident forward GEMM (igemm_fwd_patch_kernel): the gathered operand from LDS-resident patches.
+//
+// What bounds igemm_fwd_dma_kernel is the CU's L2 -> LDS intake (~35 B/clk): per K step its 192 x 208 tile takes in
+// 24 KB of im2col rows and 27 KB of filter rows for 1248 clocks of MFMA.  The im2col rows are mostly re-reads: a 5x5
+// stride-2 conv reads every input pixel for 6.25 taps, a stride-1 parity class of the backward-data GEMM for up to 9.
+// Here a workgroup's row tile covers WHOLE images, the K order of the packed filter is channel-slice-major
+// (IgArgs.fd_ck: 5 chunks = 40 channels per slice), and the source pixels a slice's taps read -- one sub-lattice of the
+// source per tap group (IgClass.grp: the four pixel parities of a stride-2 forward conv, the whole image of a stride-1
+// gather) -- are staged ONCE per (slice, group) "phase" as a patch of [image][qh][qw] 80-byte pixels (an odd number of
+// 16-byte chunks: the fragment reads spread over all banks).  The A fragment of (row, K chunk) is then a ds_read_b128
+// at  patch(phase) + (pixel(row) + dq(tap)) * 80 + j * 16,  or of a zero pixel when the tap falls outside the image:
+// a per-chunk table in LDS (built at kernel start) holds the patch buffer, j, dq and the tap's lattice offset.
+// Intake per K step drops to the filter rows plus ~4 KB of patch.
+//
+// 8 waves: 4 compute (48 rows x all 208 columns each, as igemm_fwd_dma_kernel's wave-specialised form) + 4 loaders.
+// Per K step a loader wave issues the 7 filter pieces of step s + 2 into the 3-stage ring and, in the two steps in which a
+// patch is loaded, PT_APS = 2 patch pieces; it waits with a counted vmcnt(pieces of THIS step) before the step's barrier,
+// so a piece issued in step s is visible from step s + 2.  (No filler pieces: a 1 KiB piece costs ~130 clocks of the CU's
+// intake whether or not it carries data -- with two zero-fill dummies per step the loaders were back at the MFMA time.)  Patches live in
+// PT_NPB = 3 buffers: phase p is loaded (4 pieces per wave, over 2 steps) as soon as the last step that reads phase p - 3
+// is over; the host only selects this kernel when every phase is then complete two steps before its first read
+// (plan_fwd_patch).
+// ============================================================================================
+#define PT_CK 5                        // chunks per patch pixel
+#define PT_PIXB (PT_CK * 16)
+#define PT_NPB 3                       // patch buffers
+#define PT_PIECES 16                   // 1 KiB pieces per patch, 4 per loader wave
+#define PT_PATCHB (PT_PIECES * 1024)   // <= 204 pixels
+#define PT_MAXPIX (PT_PATCHB / PT_PIXB)
+#define PT_APS 2                       // patch pieces per loader wave and K step
+#define PT_ZEROB 256                   // the zero pixel (LDS byte 0)
+
+// the bf16 epilogue of a BM x BN tile staged through LDS (shared with the forms of igemm_fwd_dma_kernel that inline it):
+// compute waves park bias + activation of their accumulators as bf16 rows, then every thread moves whole 16-byte
+// chunks of pixel rows (mask multiply, column partials: see igemm_fwd_dma_kernel)
+template <int BM, int BN, int TM, int TN, int NTHR>
+__device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char* smem, const float* sBias, bool is_mma, int row0, int col_tile0,
+                                                     int tnw, int tid, int r16, int q, int m0, int n0, int M, int tile_m,
+                                                     const IgArgs& args, const IgClass& cl) {
+  using T = bf16_t;
+  const int N = args.N, Cso = args.Cso;
+  T* out = static_cast<T*>(args.out);
+  const T* msk = static_cast<const T*>(args.mask_src);
+  const int act = args.act, mmode = args.mask_mode;
+  const float leak = args.leak;
+  constexpr int PE = BN * 2 + 16;
+  constexpr int CPR = BN * 2 / 16;
+  char* sE = smem;
+  long long* sPix = reinterpret_cast<long long*>(smem + BM * PE);
+  if (tid < BM) {
+    const int m = m0 + tid;
+    long long p = -1;
+    if (m < M) {
+      const unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
+      const unsigned rem = (unsigned)m - nb * (unsigned)(cl.GH * cl.GW);
+      const unsigned a = fd_div(rem, cl.fd_gw);
+      const unsigned b = rem - a * (unsigned)cl.GW;
+      p = (long long)(((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
+                       b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)Cso);
+    }
+    sPix[tid] = p;
+  }
+  if (is_mma) {
+    f32x4 bvs[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bvs[j] = *reinterpret_cast<const f32x4*>(sBias + (col_tile0 + j) * 16 + q * 4);
+    dispatch_act(act, [&](auto tag) {
+      constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = (col_tile0 + j) * 16 + q * 4;
+        if (j < tnw) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            f32x4 v = acc[i][j] + bvs[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act_c<ACT>(v[e], act, leak);
+            *reinterpret_cast<bf16x4*>(sE + (row0 + i * 16 + r16) * PE + col * 2) =
+                bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+          }
+        }
+      }
+    });
+  }
+  __syncthreads();
+  const float mlow = mask_low(mmode, leak);
+  constexpr int NIT = (BM * CPR + NTHR - 1) / NTHR;
+  long long pp[NIT];
+  bf16x8 mv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + NTHR * it;
+    const int row = c / CPR, cc = c - row * CPR;
+    const int n = n0 + cc * 8;
+    long long p = c < BM * CPR ? sPix[row] : -1;
+    if (n >= N) p = -1;
+    pp[it] = p;
+    mv[it] = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
+    if (mmode != TDG_MASK_NONE && p >= 0) {
+      if (n + 8 <= N) {
+        mv[it] = *reinterpret_cast<const bf16x8*>(msk + p + n);
+      } else {
+        const bf16x4 h = *reinterpret_cast<const bf16x4*>(msk + p + n);
+        mv[it][0] = h[0]; mv[it][1] = h[1]; mv[it][2] = h[2]; mv[it][3] = h[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const long long p = pp[it];
+    if (p < 0) continue;
+    const int c = tid + NTHR * it;
+    const int row = c / CPR, cc = c - row * CPR;
+    const int n = n0 + cc * 8;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
+    if (mmode != TDG_MASK_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[it][e] > 0.f ? 1.f : mlow));
+      if (args.col_partial) *reinterpret_cast<bf16x8*>(sE + row * PE + cc * 16) = v;
+    }
+    if (n + 8 <= N) {
+      *reinterpret_cast<bf16x8*>(out + p + n) = v;
+    } else {
+      *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+  if (args.col_partial) {
+    constexpr int G = NTHR / BN > 0 ? NTHR / BN : 1;
+    float* sRed = reinterpret_cast<float*>(smem + BM * PE + BM * 8);
+    __syncthreads();
+    const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW) : M;
+    const int rows_valid = max(0, min(BM, mlim - m0));
+    const int col = tid % BN, grp = tid / BN;
+    const bool bnm = args.col_mode == TDG_COL_BN;
+    if (grp < G) {
+      const float piv = bnm ? sBias[col] : 0.f;
+      float s0 = 0.f, s1 = 0.f;
+      for (int r = grp; r < rows_valid; r += G) {
+        const float v = (float)*reinterpret_cast<const bf16_t*>(sE + r * PE + col * 2) - piv;
+        s0 += v;
+        s1 += v * v;
+      }
+      sRed[(grp * 2 + 0) * BN + col] = s0;
+      sRed[(grp * 2 + 1) * BN + col] = s1;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { t0 += sRed[(g * 2 + 0) * BN + tid]; t1 += sRed[(g * 2 + 1) * BN + tid]; }
+      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * N;
+      pr[n0 + tid] = t0;
+      pr[N + n0 + tid] = t1;
+    }
+  }
+}
+
+// one K step of a compute wave: TM row tiles x TN column tiles, two 32-deep halves; A fragments at per-lane byte
+// offsets a0[i] / a1[i] (patch or zero pixel), B fragments from the ring stage (pB, swizzled chunk offsets coff0 / coff1);
+// the B fragment of tile t + 2 and the second half's A fragments are requested before the MFMAs of tile t issue
+template <int TM, int TN, int t>
+__device__ __forceinline__ void patch_mma_tile(f32x4 (&acc)[TM][TN], bf16x8 (&fa)[2][TM], bf16x8 (&fb)[2 * TN], const char* smem,
+                                               const int (&a1)[TM], const char* pB, int coff0, int coff1) {
+  constexpr int NT = 2 * TN;
+  if constexpr (t < NT) {
+    constexpr int ks = t / TN, j = t - ks * TN;
+    if constexpr (t + 2 < NT) {
+      constexpr int ks2 = (t + 2) / TN, j2 = (t + 2) - ks2 * TN;
+      fb[t + 2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
+    }
+    if constexpr (t < TM) fa[1][t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa[ks][i]);
+    __builtin_amdgcn_sched_group_barrier(0x100, (t + 2 < NT ? 1 : 0) + (t < TM ? 1 : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+    patch_mma_tile<TM, TN, t + 1>(acc, fa, fb, smem, a1, pB, coff0, coff1);
+  }
+}
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs args) {
+  using T = bf16_t;
+  constexpr int NTHR = 512, CW = 4, LW = 4;
+  constexpr int WMR = BM / CW, TM = WMR / 16, TN = BN / 16;
+  constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;      // filter rows kept per stage (whole 8-row piece pairs)
+  constexpr int NIB = BNL / 8, NBJ = (NIB + LW - 1) / LW;
+  constexpr int STAGE = BNL * IG_BKB, NS = 3;
+  constexpr int NPL = NBJ + PT_APS;                       // pieces per loader wave and step
+  static_assert(NPL == 9, "the counted waits below are written for 7 filter + 2 patch pieces");
+  static_assert(BM % (16 * CW) == 0 && BN % 16 == 0, "tile config");
+  // LDS map: [zero pixel + dummy landing zones | filter ring | patches | chunk table | bias row].  The zero pixel sits at
+  // byte 0, so "this tap is outside the image" is an AND of the fragment address with 0.
+  constexpr int OFF_ZERO = 0, OFF_RING = PT_ZEROB, OFF_PATCH = OFF_RING + NS * STAGE, OFF_TAB = OFF_PATCH + PT_NPB * PT_PATCHB;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const IgClass& cl = args.cls[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / args.ntiles_n;
+  const int tile_n = bid - tile_m * args.ntiles_n;
+  const int M = cl.M;
+  const int nsteps = cl.nsteps;
+  int* sTab = reinterpret_cast<int*>(smem + OFF_TAB);
+  float* sBias = reinterpret_cast<float*>(smem + OFF_TAB + nsteps * 8 * 8);
+  if (tile_m * BM >= M) {                              // a class with fewer rows than the largest: its partial rows are zeros
+    if (args.col_partial && tid < BN) {
+      const int n = args.n_begin + tile_n * BN + tid;
+      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * args.N;
+      if (n < args.N) { pr[n] = 0.f; pr[args.N + n] = 0.f; }
+    }
+    return;
+  }
+  const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const bool is_mma = wave < CW;
+  const int ntaps = cl.ntaps, G = cl.ngroups, QH = cl.QH, QW = cl.QW;
+  const int GHW = cl.GH * cl.GW;
+  const int SLC = ntaps * PT_CK;                       // chunks per slice
+  const int P = args.nslices * G;                      // phases
+
+  // ---- tables: bias row, zero pixel, per-chunk A table ------------------------------------------------------------
+  const float bias_v = (tid < BNL && args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
+  if (tid < PT_ZEROB / 4) reinterpret_cast<int*>(smem + OFF_ZERO)[tid] = 0;
+  // lane t (< 32) holds tap t of the class: group, lattice offsets (+8, unsigned nibbles) -- read with lane crossbars below
+  // instead of per-entry kernel-argument loads
+  int tapvec;
+  {
+    const int t = lane & 31;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) gi += (k < G && t >= cl.grp[k].t0) ? 1 : 0;
+    const int pk = cl.tap[t];
+    const int dhq = (tap_dh(pk) - cl.grp[gi].ph) / args.sigma, dwq = (tap_dw(pk) - cl.grp[gi].pw) / args.sigma;   // exact by construction
+    tapvec = gi | ((dhq + 8) << 4) | ((dwq + 8) << 8);
+  }
+  // chunk table, two words per K chunk: the fragment's byte address minus the row's pixel offset (patch buffer, dq pixels,
+  // chunk j) and the tap's index = the bit of the row's validity mask to test (31: K padding, never set)
+  for (int g0 = 0; g0 < nsteps * 8; g0 += NTHR) {
+    const int g = g0 + tid;
+    const unsigned u = fd_div((unsigned)g, args.fd_ck);
+    const int j = g - (int)u * PT_CK;
+    const unsigned sl = fd_div(u, cl.fd_nt);
+    const int t = (int)(u - sl * (unsigned)ntaps);
+    const int tv = __builtin_amdgcn_ds_bpermute((t & 31) << 2, tapvec);
+    int w0 = 0, w1 = 31;
+    if ((int)sl < args.nslices) {
+      const int gi = tv & 15, dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
+      const int p = (int)sl * G + gi;
+      const int buf = p - (p / PT_NPB) * PT_NPB;
+      w0 = OFF_PATCH + buf * PT_PATCHB + (dhq * QW + dwq) * PT_PIXB + j * 16;
+      w1 = t;
+    }
+    if (g < nsteps * 8) {
+      sTab[2 * g] = w0;
+      sTab[2 * g + 1] = w1;
+    }
+  }
+  if (tid < BNL) sBias[tid] = bias_v;
+
+  const int r16 = lane & 15, q = lane >> 4;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (!is_mma) {
+    // ================================ loader waves ================================
+    const int lwave = wave - CW;
+    const int par = lwave & 1, wh = lwave >> 1, rsub = lane >> 3;
+    const __amdgpu_buffer_rsrc_t rA = make_rsrc(args.src, args.src_bytes);
+    const __amdgpu_buffer_rsrc_t rB = make_rsrc(static_cast<const char*>(args.wpack) + cl.w_off_bytes, args.w_bytes - cl.w_off_bytes);
+    const int lch = (lane & 7) ^ ((4 * par + (rsub >> 1)) & 7);       // this lane's logical K chunk of a filter row (source-side swizzle)
+    unsigned b_row[NBJ];
+    int b_lds[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+      const int I = 2 * (wh + (LW / 2) * j) + par;
+      const int n = n0 + 8 * I + rsub;
+      const bool useful = 8 * I < BN;
+      b_row[j] = (useful && n < args.N) ? ((unsigned)n * (unsigned)cl.Kp + (unsigned)(lch * 8)) * 2u : OOB_OFFSET;
+      b_lds[j] = (I < NIB ? I : NIB - 1) * 1024;
+    }
+    auto b_pieces = [&](int step) {                  // the filter rows of K step `step` into its ring stage (zero fill past the last step)
+      const int st = step - (step / NS) * NS;
+      char* stage = smem + OFF_RING + st * STAGE;
+      const unsigned kb = step < nsteps ? (unsigned)step * IG_BKB : OOB_OFFSET;
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) {
+        const unsigned off = (b_row[j] == OOB_OFFSET || kb == OOB_OFFSET) ? OOB_OFFSET : b_row[j] + kb;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rB, (lds_ptr_t)(stage + b_lds[j]), 16, off, 0, 0, 0);
+      }
+    };
+    // phase p = slice * G + group, walked incrementally: (slice, group, patch buffer) of the next phase to load and of
+    // the phase PT_NPB behind it, whose last reading step frees that buffer
+    struct Ph { int sl, gi, buf; };
+    auto ph_next = [&](Ph& x) {
+      if (++x.gi == G) { x.gi = 0; ++x.sl; }
+      x.buf = x.buf == PT_NPB - 1 ? 0 : x.buf + 1;
+    };
+    auto ph_end_chunk = [&](const Ph& x) { return x.sl * SLC + (cl.grp[x.gi].t0 + cl.grp[x.gi].nt) * PT_CK; };
+    auto ph_delta = [&](const Ph& x) { return (unsigned)(((cl.grp[x.gi].ph * args.SW + cl.grp[x.gi].pw) * args.Cs + x.sl * PT_CK * 8) * 2); };
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's table / zero-pixel stores are done before any LDS-DMA is pending
+    // ---- prologue: ring stages 0 and 1 first (their lane constants are cheap), then the first PT_NPB patches
+    b_pieces(0);
+    b_pieces(1);
+    // patch pieces: piece ps * 4 + lwave of a patch, 64 consecutive 16-byte chunks of its [pixel][PT_CK] image
+    const int IPT = BM / GHW;                          // images per row tile
+    const int nimg = M / GHW;
+    unsigned a_src[PT_PIECES / LW];
+#pragma unroll
+    for (int ps = 0; ps < PT_PIECES / LW; ++ps) {
+      const int c = (ps * LW + lwave) * 64 + lane;
+      const int pl = c / PT_CK, j = c - pl * PT_CK;
+      const unsigned il = fd_div((unsigned)pl, cl.fd_qhw);
+      const int rem = pl - (int)il * QH * QW;
+      const int qh = (int)fd_div((unsigned)rem, cl.fd_qw), qw = rem - qh * QW;
+      const int img = tile_m * IPT + (int)il;
+      const bool ok = (int)il < IPT && img < nimg;
+      a_src[ps] = ok ? (unsigned)((((img * args.SH + args.sigma * qh) * args.SW + args.sigma * qw) * args.Cs + j * 8) * 2) : OOB_OFFSET;
+    }
+    auto a_piece = [&](const Ph& x, unsigned delta, auto ps_c) {
+      constexpr int ps = decltype(ps_c)::value;
+      const unsigned off = a_src[ps] == OOB_OFFSET ? OOB_OFFSET : a_src[ps] + delta;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(smem + OFF_PATCH + x.buf * PT_PATCHB + (ps * LW + lwave) * 1024), 16, off, 0, 0, 0);
+    };
+    Ph pn{0, 0, 0};
+    for (int p = 0; p < PT_NPB; ++p) {
+      if (p < P) {
+        const unsigned dl = ph_delta(pn);
+        a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
+        ph_next(pn);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Ph pf{0, 0, 0};                                      // the phase whose buffer pn takes over
+    int left = P - PT_NPB;                               // phases still to load
+    int ready = left > 0 ? (ph_end_chunk(pf) - 1) / 8 + 1 : (1 << 30);
+    unsigned dl = left > 0 ? ph_delta(pn) : 0u;
+    for (int step = 0; step < nsteps; ++step) {
+      b_pieces(step + 2);
+      bool patch = true;
+      if (step == ready) {
+        a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{});
+      } else if (step == ready + 1) {
+        a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
+        ph_next(pn);
+        ph_next(pf);
+        --left;
+        ready = left > 0 ? max((ph_end_chunk(pf) - 1) / 8 + 1, step + 1) : (1 << 30);
+        dl = left > 0 ? ph_delta(pn) : 0u;
+      } else {
+        patch = false;
+      }
+      // leave exactly this step's pieces in flight
+      if (step == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (patch) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+    // ================================ compute waves ================================
+    // per row tile: the row's pixel offset inside a patch and a validity bit per tap (bit t: tap t reads inside the image)
+    int base_i[TM], mask_i[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int loc = wave * WMR + i * 16 + r16;
+      const bool ok = m0 + loc < M;
+      const unsigned il = fd_div((unsigned)loc, cl.fd_ghw);
+      const int rem = loc - (int)il * GHW;
+      const int a = (int)fd_div((unsigned)rem, cl.fd_gw), b = rem - a * cl.GW;
+      base_i[i] = (((int)il * QH + a) * QW + b) * PT_PIXB;
+      int mk = 0;
+      for (int t = 0; t < ntaps; ++t) {
+        const int tv = __builtin_amdgcn_readlane(tapvec, t);
+        const int dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
+        const int v = (ok & ((unsigned)(a + dhq) < (unsigned)QH) & ((unsigned)(b + dwq) < (unsigned)QW)) ? 1 : 0;
+        mk |= v << t;
+      }
+      mask_i[i] = mk;
+    }
+    const int swl = (r16 >> 1) & 7;
+    const int coff0 = ((0 * 4 + q) ^ swl) << 4, coff1 = ((1 * 4 + q) ^ swl) << 4;
+    // fragment byte address: (row offset + chunk word 0) where the tap is inside the image, 0 (the zero pixel) elsewhere:
+    // a signed 1-bit field extract of the validity mask is the AND mask -- three plain vector instructions, no branch
+    auto a_offsets = [&](const i32x2& e, int (&o)[TM]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) o[i] = (base_i[i] + e[0]) & __builtin_amdgcn_sbfe(mask_i[i], e[1], 1);
+    };
+    const i32x2* sTab2 = reinterpret_cast<const i32x2*>(sTab);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // tables, zero pixel, first patches, ring stage 0
+    int a0[TM], a1[TM];
+    a_offsets(sTab2[q], a0);
+    a_offsets(sTab2[4 + q], a1);
+    i32x2 e0 = sTab2[(nsteps > 1 ? 8 : 0) + q], e1 = sTab2[(nsteps > 1 ? 8 : 0) + 4 + q];     // step 1's chunks
+    for (int step = 0; step < nsteps; ++step) {
+      const int st = step - (step / NS) * NS;
+      const char* pB = smem + OFF_RING + st * STAGE + r16 * IG_BKB;
+      bf16x8 fa[2][TM];
+      bf16x8 fb[2 * TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a0[i]);
+      fb[0] = *reinterpret_cast<const bf16x8*>(pB + coff0);
+      fb[1] = *reinterpret_cast<const bf16x8*>(pB + 16 * IG_BKB + coff0);
+      __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
+      patch_mma_tile<TM, TN, 0>(acc, fa, fb, smem, a1, pB, coff0, coff1);
+      // the next step's fragment addresses (from the chunk words read a step ago) and the chunk words of the step after
+      a_offsets(e0, a0);
+      a_offsets(e1, a1);
+      const int s2 = step + 2 < nsteps ? step + 2 : step;
+      e0 = sTab2[s2 * 8 + q];
+      e1 = sTab2[s2 * 8 + 4 + q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- epilogue (every DMA has landed: the loaders' last wait is vmcnt(0)) ----------------------------------------------
+  static_assert(BM * (BN * 2 + 16) + BM * 8 + 2 * (NTHR / BN) * BN * 4 <= OFF_TAB, "epilogue staging must not reach the tables");   // (it overlays zero pixel, ring and patches)
+  staged_epilogue_bf16<BM, BN, TM, TN, NTHR>(acc, smem, sBias, is_mma, wave * WMR, 0, TN, tid, r16, q, m0, n0, M, tile_m, args, cl);
+}
+
 // Second half of a split-K forward-type GEMM: out[pixel(m)][n] = epilogue(sum over splits of slab[split][class][m][n]).
 // One thread per (class, row, 4 columns); splits are added in ascending order (deterministic).
 template <typename T>
@@ -2501,6 +2927,93 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
   return TDG_OK;
 }
 
+// igemm_fwd_patch_kernel: does it apply to this launch?  Fills the tap groups / lattice of every class when it does.
+// Conditions (each one is what the kernel's indexing assumes): bf16 vector gather, 5-chunk K slices, 208-column tiles with
+// the staged epilogue, row tiles of whole images, a source whose sub-lattices all have the same [QH, QW] shape, patches of
+// <= PT_MAXPIX pixels, tap groups in K order, and a phase schedule in which every patch lands two steps before its first
+// read (the loader's own rule, simulated here).
+template <int BM>
+bool plan_fwd_patch(IgArgs& a, int mmax) {
+  const int enabled = getenv("TDG_PATCH") ? atoi(getenv("TDG_PATCH")) : 1;     // diagnostics: 0 = igemm_fwd_dma_kernel, 2 = also on small grids
+  if (!enabled || (int)a.fd_ck.d != PT_CK || a.accumulate || (a.N & 3) || (a.Cso & 3)) return false;
+  if (a.sigma < 1 || a.sigma > 2 || a.SH % a.sigma || a.SW % a.sigma) return false;
+  const int QH = a.SH / a.sigma, QW = a.SW / a.sigma;
+  if (QW > 32 || QH > 64) return false;
+  if (enabled != 2 && (long long)tdg_ceil_div(mmax, BM) * tdg_ceil_div(a.N, 208) * a.nclasses < 192) return false;   // small grids: the 128-row / 112-column forms
+  for (int ci = 0; ci < a.nclasses; ++ci) {
+    IgClass& c = a.cls[ci];
+    const int ghw = c.GH * c.GW;
+    if (ghw <= 0 || BM % ghw || c.M % ghw) return false;
+    if ((BM / ghw) * QH * QW > PT_MAXPIX || c.GH > QH + 8 || c.GW > QW + 8) return false;
+    if (c.nsteps < 4 || c.nsteps * 64 > 16384 || c.ntaps > 31) return false;
+    // tap groups: consecutive taps with equal (dh mod sigma, dw mod sigma)
+    int ng = 0;
+    for (int t = 0; t < c.ntaps; ++t) {
+      const int dh = (signed char)(c.tap[t] & 0xff), dw = (signed char)((c.tap[t] >> 8) & 0xff);
+      const int ph = ((dh % a.sigma) + a.sigma) % a.sigma, pw = ((dw % a.sigma) + a.sigma) % a.sigma;
+      const int dhq = (dh - ph) / a.sigma, dwq = (dw - pw) / a.sigma;
+      if (dhq < -8 || dhq > 7 || dwq < -8 || dwq > 7 || dhq * QW + dwq < -127 || dhq * QW + dwq > 127) return false;
+      if (ng && c.grp[ng - 1].ph == ph && c.grp[ng - 1].pw == pw) { ++c.grp[ng - 1].nt; continue; }
+      for (int g = 0; g < ng; ++g)
+        if (c.grp[g].ph == ph && c.grp[g].pw == pw) return false;     // a group split in two: not the K order this kernel wants
+      if (ng == 4) return false;
+      c.grp[ng].t0 = (short)t; c.grp[ng].nt = 1; c.grp[ng].ph = (short)ph; c.grp[ng].pw = (short)pw;
+      ++ng;
+    }
+    c.ngroups = ng; c.QH = QH; c.QW = QW;
+    c.fd_qhw = make_fastdiv(QH * QW); c.fd_qw = make_fastdiv(QW);
+    // the loader's schedule: phase p (>= PT_NPB) is issued in steps s_p, s_p + 1 and is visible from step s_p + 3
+    const int P = a.nslices * ng, slc = c.ntaps * PT_CK;
+    auto first_chunk = [&](int p) { return (p / ng) * slc + c.grp[p % ng].t0 * PT_CK; };
+    auto end_chunk = [&](int p) { return (p / ng) * slc + (c.grp[p % ng].t0 + c.grp[p % ng].nt) * PT_CK; };
+    int prev_issue = -2;
+    for (int p = PT_NPB; p < P; ++p) {
+      const int ready = (end_chunk(p - PT_NPB) - 1) / 8 + 1;
+      const int issue = ready > prev_issue + 2 ? ready : prev_issue + 2;
+      if (first_chunk(p) / 8 < issue + 3) return false;
+      prev_issue = issue;
+    }
+  }
+  return true;
+}
+
+template <int BM, int BN>
+int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
+  a.n_begin = 0;
+  a.ntiles_n = tdg_ceil_div(a.N, BN);
+  a.ntiles_m_max = tdg_ceil_div(mmax, BM);
+  if (t_col) {
+    const int nblk = a.nclasses * a.ntiles_m_max;
+    if ((size_t)nblk * 2 * a.N * sizeof(float) <= t_col->col_partial_bytes) {
+      a.col_partial = t_col->col_partial;
+      a.col_mode = t_col->col_mode;
+      a.col_images = t_col->col_images;
+      *t_col->col_nblk_out = nblk;
+    }
+  }
+  a.ksplit = 1;
+  a.steps_per_split = 1 << 30;
+  a.slab = nullptr;
+  int smax = 0;
+  for (int c = 0; c < a.nclasses; ++c) smax = a.cls[c].nsteps > smax ? a.cls[c].nsteps : smax;
+  constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
+  const size_t lds = PT_ZEROB + 3 * (size_t)BNL * IG_BKB + PT_NPB * PT_PATCHB + (size_t)smax * 64 + BNL * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_patch_kernel<bf16,%d,%d>", BM, BN);
+  tdg_note_kernel(name);
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  tdg_timing_start(name, t_flops, s);
+  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN>), grid, block, lds, s, a);
+  tdg_timing_stop(s);
+  TDG_HIP_LAUNCH_CHECK("igemm_fwd_patch");
+  return TDG_OK;
+}
+
 template <typename T>
 int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   constexpr int BM = 128;
@@ -2516,6 +3029,11 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   // large problems: 256-row tiles fed by LDS-DMA (needs >= ~1 workgroup per CU to pay off)
   // 208-column problems with a vector gather always take the LDS-DMA kernel (measured faster than the
   // register-staged one even when the grid does not fill the chip)
+  if constexpr (sizeof(T) == 2) {
+    // whole-image row tiles with the gathered operand resident in LDS (igemm_fwd_patch_kernel)
+    if (veca && bn == 208 && dma_mode == 1 && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW") && plan_fwd_patch<192>(a, mmax))
+      return launch_fwd_patch<192, 208>(a, mmax, s);
+  }
   if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
     // one 8-wave workgroup per CU.  Row tiles: 256 (2-stage LDS ring), 192 and 128 (3-stage ring, loads two
     // steps ahead).  (Covering 400 = 208 + 192 / 800 = 2 x 208 + 2 x 192 columns exactly with a second launch of

@@ -90,7 +90,7 @@ def test_headline_conv_launches_bf16(case):
     big.set(x)
     conv.fwd(big.ptr(), small.ptr(), n, K.epilogue(bias=torch.tensor(b, device=dev), act=K.ACT_LRELU, leak=0.2))
     kern = last_kernel()
-    assert 'igemm_fwd_dma_kernel<bf16' in kern and ',208,' in kern, kern
+    assert 'igemm_fwd_patch_kernel<bf16,192,208>' in kern, kern
     got = small.get()
     ref = T.lrelu(T.conv2d(x[idx].astype(np.float64), W64, s) + b)
     assert relerr(got[idx], ref) < BF16_TOL, kern
@@ -105,7 +105,7 @@ def test_headline_conv_launches_bf16(case):
     out = big.like()
     conv.bwd_data(small.ptr(), out.ptr(), n, K.epilogue(mask_mode=K.MASK_LRELU, mask_src=mask.ptr(), leak=0.2))
     kern = last_kernel()
-    assert 'igemm_fwd_dma_kernel<bf16' in kern and ',208,' in kern, kern
+    assert 'igemm_fwd_patch_kernel<bf16,192,208>' in kern, kern
     got = out.get()
     ref = T.conv2d_backprop_input((len(idx), h, w, cin), W64, dy[idx].astype(np.float64), s) * \
         T.lrelu_grad_mask(x[idx].astype(np.float64))

@@ -177,6 +177,29 @@ def test_conv_lds_dma_variant(case, dtype, monkeypatch):
     for nw in ('8',):                            # the 192-row tile with every wave loading and computing (default: wave-specialised)
         monkeypatch.setenv('TDG_DMA_NW', nw)
         test_conv_fwd_bwd(case, dtype)
+    monkeypatch.delenv('TDG_DMA')
+    monkeypatch.delenv('TDG_DMA_NW')
+    monkeypatch.setenv('TDG_PATCH', '2')         # the patch-resident kernel (whole-image row tiles) where its plan applies
+    test_conv_fwd_bwd(case, dtype)
+
+
+@pytest.mark.parametrize('case', [(7, 16, 16, 200, 400, 5, 2), (25, 8, 8, 400, 800, 5, 2), (13, 8, 8, 200, 200, 5, 2), (6, 16, 16, 40, 200, 5, 2),
+                                  (5, 8, 8, 200, 400, 3, 1), (4, 16, 16, 400, 200, 4, 2)])
+def test_conv_patch_resident_kernel(case, monkeypatch):
+    """igemm_fwd_patch_kernel forced onto small problems: ragged last row tile (images % images-per-tile != 0), every parity
+    class of the backward-data GEMM, a stride-1 conv, 4x4 filters, one and many K slices; the dispatch is asserted."""
+    K = pkg('kernels')
+    monkeypatch.setenv('TDG_PATCH', '2')
+    test_conv_fwd_bwd(case, 1)
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    oh, pt, _ = T.same_pad(h, k, s)
+    ow, pl, _ = T.same_pad(w, k, s)
+    big, small = K.Act(n, h, w, cin, K.BF16, dev), K.Act(n, oh, ow, cout, K.BF16, dev)
+    conv = K.Conv(big, small, k, k, s, pt, pl)
+    conv.pack(torch.zeros(k, k, cin, cout, device=dev))
+    conv.fwd(big.ptr(), small.ptr(), n)
+    assert 'igemm_fwd_patch_kernel' in pkg('_lib').load().tdg_last_kernel().decode()
 
 
 @pytest.mark.parametrize('dtype', [0, 1])

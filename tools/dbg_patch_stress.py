@@ -1,0 +1,47 @@
+"""Diagnostics: run-to-run determinism of igemm_fwd_patch_kernel (a race shows as a run that differs from the first)."""
+import importlib, os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+K = importlib.import_module('3dgan_amd.kernels')
+L = importlib.import_module('3dgan_amd._lib')
+
+def run(n, h, w, cin, cout, k, s, reps):
+    dev = torch.device('cuda:0')
+    oh, ow = -(-h // s), -(-w // s)
+    pt = max((oh - 1) * s + k - h, 0) // 2
+    big, small = K.Act(n, h, w, cin, K.BF16, dev), K.Act(n, oh, ow, cout, K.BF16, dev)
+    g = torch.Generator().manual_seed(1)
+    big.buf.copy_(torch.randn(big.buf.numel(), generator=g).to(dev).bfloat16())
+    small.buf.copy_(torch.randn(small.buf.numel(), generator=g).to(dev).bfloat16())
+    conv = K.Conv(big, small, k, k, s, pt, pt)
+    conv.pack((torch.randn(k, k, cin, cout, generator=g) * 0.05).to(dev))
+    junk = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    for name in ('fwd', 'bwd_data'):
+        ref = None
+        nbad = 0
+        for r in range(reps):
+            if r % 3 == 1:
+                junk.normal_()                    # disturb caches / timing between launches
+            if name == 'fwd':
+                o = small.like(); conv.fwd(big.ptr(), o.ptr(), n); shape = (n, oh, ow, small.cs)
+            else:
+                o = big.like(); conv.bwd_data(small.ptr(), o.ptr(), n); shape = (n, h, w, big.cs)
+            cur = o.buf.float()
+            if ref is None:
+                ref = cur.clone()
+                print(name, L.load().tdg_last_kernel().decode())
+                continue
+            if not torch.equal(ref, cur):
+                nbad += 1
+                bad = ((ref - cur).abs() > 0).reshape(shape)
+                idx = bad.nonzero()
+                ch = torch.unique(idx[:, 3])
+                print(name, 'rep', r, 'differs:', int(bad.sum()), 'elements; images', torch.unique(idx[:, 0]).tolist()[:30], 'rows', torch.unique(idx[:, 1]).tolist(),
+                      'cols', torch.unique(idx[:, 2]).tolist(), 'channels', len(ch), int(ch.min()), int(ch.max()), flush=True)
+        print(name, 'reps', reps, 'differing runs', nbad, flush=True)
+
+if __name__ == '__main__':
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    run(1536, 8, 8, 400, 800, 5, 2, reps)
+    run(1536, 16, 16, 200, 400, 5, 2, reps)
