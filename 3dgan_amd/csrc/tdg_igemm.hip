@@ -1133,29 +1133,44 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
   }
 }
 
-// one K step of a compute wave: TM row tiles x TN column tiles, two 32-deep halves; A fragments at per-lane byte
-// offsets a0[i] / a1[i] (patch or zero pixel), B fragments from the ring stage (pB, swizzled chunk offsets coff0 / coff1);
-// the B fragment of tile t + 2 and the second half's A fragments are requested before the MFMAs of tile t issue
+// One K step of a compute wave -- TM row tiles x TN column tiles x two 32-deep halves = 2 TN "tiles" of TM MFMAs -- as a
+// chain that never drains: B fragment t + 2 is requested before the MFMAs of tile t issue, and the chain runs ACROSS the
+// step boundary.  First half (tiles 0 .. TN-1, K chunks 0-3): A fragments fa0 (loaded during the previous step), second
+// half's A fragments fa1 requested behind the first tiles.  Second half (after the step's "data ready" barrier): the NEXT
+// step's fa0 are requested into the registers the first half has finished with, and the last two tiles request the next
+// step's B fragments 0 and 1 from the next ring stage.  fb is indexed by tile; fb[2 TN], fb[2 TN + 1] carry over.
 template <int TM, int TN, int t>
-__device__ __forceinline__ void patch_mma_tile(f32x4 (&acc)[TM][TN], bf16x8 (&fa)[2][TM], bf16x8 (&fb)[2 * TN], const char* smem,
-                                               const int (&a1)[TM], const char* pB, int coff0, int coff1) {
+__device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (&fa0)[TM], bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
+                                            const char* smem, const int (&a1)[TM], const char* pB, int coff0, int coff1) {
+  if constexpr (t < TN) {
+    constexpr int t2 = t + 2, ks2 = t2 / TN, j2 = t2 - ks2 * TN;
+    fb[t2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
+    if constexpr (t < TM) fa1[t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][t], fb[t], fa0[i]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + (t < TM ? 1 : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+    patch_half0<TM, TN, t + 1>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
+  }
+}
+template <int TM, int TN, int t>
+__device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[TM], const bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
+                                            const char* smem, const int (&a0n)[TM], const char* pB, const char* pBn, int coff0, int coff1) {
   constexpr int NT = 2 * TN;
   if constexpr (t < NT) {
-    constexpr int ks = t / TN, j = t - ks * TN;
-    if constexpr (t + 2 < NT) {
-      constexpr int ks2 = (t + 2) / TN, j2 = (t + 2) - ks2 * TN;
-      fb[t + 2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
-    }
-    if constexpr (t < TM) fa[1][t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
+    constexpr int j = t - TN, t2 = t + 2;
+    if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
+    else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's tiles 0 and 1
+    if constexpr (j >= 1 && j <= TM) fa0[j - 1] = *reinterpret_cast<const bf16x8*>(smem + a0n[j - 1]);   // (tile TN no longer reads fa0)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa[ks][i]);
-    __builtin_amdgcn_sched_group_barrier(0x100, (t + 2 < NT ? 1 : 0) + (t < TM ? 1 : 0), 0);
+    for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa1[i]);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((j >= 1 && j <= TM) ? 1 : 0), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-    patch_mma_tile<TM, TN, t + 1>(acc, fa, fb, smem, a1, pB, coff0, coff1);
+    patch_half1<TM, TN, t + 1>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int PF>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs args) {
   using T = bf16_t;
   constexpr int NTHR = 512, CW = 4, LW = 4;
@@ -1197,6 +1212,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
   const int SLC = ntaps * PT_CK;                       // chunks per slice
   const int P = args.nslices * G;                      // phases
 
+  unsigned long long ph0 = 0, ph1 = 0, t0 = 0, t1 = 0, t2 = 0, s_issue = 0, s_mma = 0, s_sync = 0;   // stamps (diagnostic build only)
+  TDG_STAMP(ph0);
   // ---- tables: bias row, zero pixel, per-chunk A table ------------------------------------------------------------
   const float bias_v = (tid < BNL && args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
   if (tid < PT_ZEROB / 4) reinterpret_cast<int*>(smem + OFF_ZERO)[tid] = 0;
@@ -1318,6 +1335,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     int ready = left > 0 ? (ph_end_chunk(pf) - 1) / 8 + 1 : (1 << 30);
     unsigned dl = left > 0 ? ph_delta(pn) : 0u;
     for (int step = 0; step < nsteps; ++step) {
+      TDG_STAMP(t0);
       b_pieces(step + 2);
       bool patch = true;
       if (step == ready) {
@@ -1332,11 +1350,15 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       } else {
         patch = false;
       }
+      TDG_STAMP(t1);
       // leave exactly this step's pieces in flight
       if (step == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else if (patch) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                        // A: every piece issued before this step has landed
+      __builtin_amdgcn_s_barrier();                        // B: the compute waves are done with this step's stage
+      TDG_STAMP(t2);
+      s_issue += t1 - t0; s_sync += t2 - t1;
     }
   } else {
     // ================================ compute waves ================================
@@ -1374,31 +1396,65 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     a_offsets(sTab2[q], a0);
     a_offsets(sTab2[4 + q], a1);
     i32x2 e0 = sTab2[(nsteps > 1 ? 8 : 0) + q], e1 = sTab2[(nsteps > 1 ? 8 : 0) + 4 + q];     // step 1's chunks
-    for (int step = 0; step < nsteps; ++step) {
-      const int st = step - (step / NS) * NS;
-      const char* pB = smem + OFF_RING + st * STAGE + r16 * IG_BKB;
-      bf16x8 fa[2][TM];
-      bf16x8 fb[2 * TN];
+    bf16x8 fa0[TM], fa1[TM];
+    bf16x8 fb[2 * TN + 2];
+    {
+      const char* pB = smem + OFF_RING + r16 * IG_BKB;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + a0[i]);
+      for (int i = 0; i < TM; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(smem + a0[i]);
       fb[0] = *reinterpret_cast<const bf16x8*>(pB + coff0);
       fb[1] = *reinterpret_cast<const bf16x8*>(pB + 16 * IG_BKB + coff0);
-      __builtin_amdgcn_sched_group_barrier(0x100, TM + 2, 0);
-      patch_mma_tile<TM, TN, 0>(acc, fa, fb, smem, a1, pB, coff0, coff1);
+    }
+    int st = 0;
+    for (int step = 0; step < nsteps; ++step) {
+      TDG_STAMP(t0);
+      const int stn = st == NS - 1 ? 0 : st + 1;
+      const char* pB = smem + OFF_RING + st * STAGE + r16 * IG_BKB;
+      const char* pBn = smem + OFF_RING + stn * STAGE + r16 * IG_BKB;
       // the next step's fragment addresses (from the chunk words read a step ago) and the chunk words of the step after
-      a_offsets(e0, a0);
-      a_offsets(e1, a1);
+      int a0n[TM], a1n[TM];
+      a_offsets(e0, a0n);
+      a_offsets(e1, a1n);
       const int s2 = step + 2 < nsteps ? step + 2 : step;
       e0 = sTab2[s2 * 8 + q];
       e1 = sTab2[s2 * 8 + 4 + q];
+      patch_half0<TM, TN, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
+      __builtin_amdgcn_s_barrier();                      // A: the loaders have seen step + 1's pieces land
+      patch_half1<TM, TN, TN>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
+      fb[0] = fb[2 * TN];
+      fb[1] = fb[2 * TN + 1];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a1[i] = a1n[i];
+      st = stn;
+      TDG_STAMP(t1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_barrier();                      // B: this stage and the patches read in this step may be overwritten
+      TDG_STAMP(t2);
+      s_mma += t1 - t0; s_sync += t2 - t1;
     }
   }
+  TDG_STAMP(ph1);
+#ifdef TDG_STAMPS
+  if (args.stamps && lane == 0) {
+    unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+    o[0] = s_issue; o[1] = s_mma; o[2] = s_sync; o[3] = (unsigned long long)nsteps;
+  }
+#endif
 
   // ---- epilogue (every DMA has landed: the loaders' last wait is vmcnt(0)) ----------------------------------------------
   static_assert(BM * (BN * 2 + 16) + BM * 8 + 2 * (NTHR / BN) * BN * 4 <= OFF_TAB, "epilogue staging must not reach the tables");   // (it overlays zero pixel, ring and patches)
   staged_epilogue_bf16<BM, BN, TM, TN, NTHR>(acc, smem, sBias, is_mma, wave * WMR, 0, TN, tid, r16, q, m0, n0, M, tile_m, args, cl);
+#ifdef TDG_STAMPS
+  if (args.stamps) {
+    unsigned long long ph3 = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(ph3);
+    if (lane == 0) {
+      unsigned long long* o = args.stamps + 262144 + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o[0] = ph0; o[1] = ph1; o[2] = ph1; o[3] = ph3;
+    }
+  }
+#endif
 }
 
 // Second half of a split-K forward-type GEMM: out[pixel(m)][n] = epilogue(sum over splits of slab[split][class][m][n]).
@@ -2939,7 +2995,7 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
   if (a.sigma < 1 || a.sigma > 2 || a.SH % a.sigma || a.SW % a.sigma) return false;
   const int QH = a.SH / a.sigma, QW = a.SW / a.sigma;
   if (QW > 32 || QH > 64) return false;
-  if (enabled != 2 && (long long)tdg_ceil_div(mmax, BM) * tdg_ceil_div(a.N, 208) * a.nclasses < 192) return false;   // small grids: the 128-row / 112-column forms
+  if (enabled != 2 && (long long)tdg_ceil_div(mmax, BM) * tdg_ceil_div(a.N, 208) * a.nclasses < 160) return false;   // small grids: the 112-column forms
   for (int ci = 0; ci < a.nclasses; ++ci) {
     IgClass& c = a.cls[ci];
     const int ghw = c.GH * c.GW;
@@ -3000,7 +3056,7 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   const size_t lds = PT_ZEROB + 3 * (size_t)BNL * IG_BKB + PT_NPB * PT_PATCHB + (size_t)smax * 64 + BNL * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   static char name[64] = "";
@@ -3008,7 +3064,7 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   tdg_note_kernel(name);
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
   tdg_timing_start(name, t_flops, s);
-  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 2>), grid, block, lds, s, a);
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_patch");
   return TDG_OK;
@@ -3030,9 +3086,19 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   // 208-column problems with a vector gather always take the LDS-DMA kernel (measured faster than the
   // register-staged one even when the grid does not fill the chip)
   if constexpr (sizeof(T) == 2) {
-    // whole-image row tiles with the gathered operand resident in LDS (igemm_fwd_patch_kernel)
-    if (veca && bn == 208 && dma_mode == 1 && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW") && plan_fwd_patch<192>(a, mmax))
-      return launch_fwd_patch<192, 208>(a, mmax, s);
+    // whole-image row tiles with the gathered operand resident in LDS (igemm_fwd_patch_kernel), 192 or 128 rows: the
+    // same cost model as below (rounds of 256 one-per-CU workgroups x rows per tile / relative efficiency; measured on the
+    // 1536-image GEMMs: 8 - 13 % less time than igemm_fwd_dma_kernel's 192-row form)
+    if (veca && bn == 208 && dma_mode == 1 && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW")) {
+      const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
+      const double c192 = (double)tdg_ceil_div(per * tdg_ceil_div(mmax, 192), 256) * 192 / 1.0;
+      const double c128 = (double)tdg_ceil_div(per * tdg_ceil_div(mmax, 128), 256) * 128 / 0.85;
+      const int pbm = getenv("TDG_PATCH_BM") ? atoi(getenv("TDG_PATCH_BM")) : 0;            // diagnostics: force a row tile
+      const bool want128 = pbm ? pbm == 128 : c128 < c192 - 1e-9;
+      if (want128 && plan_fwd_patch<128>(a, mmax)) return launch_fwd_patch<128, 208>(a, mmax, s);
+      if (plan_fwd_patch<192>(a, mmax)) return launch_fwd_patch<192, 208>(a, mmax, s);
+      if (!want128 && !pbm && plan_fwd_patch<128>(a, mmax)) return launch_fwd_patch<128, 208>(a, mmax, s);
+    }
   }
   if (veca && bn == 208 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
     // one 8-wave workgroup per CU.  Row tiles: 256 (2-stage LDS ring), 192 and 128 (3-stage ring, loads two

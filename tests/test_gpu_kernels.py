@@ -191,6 +191,9 @@ def test_conv_patch_resident_kernel(case, monkeypatch):
     K = pkg('kernels')
     monkeypatch.setenv('TDG_PATCH', '2')
     test_conv_fwd_bwd(case, 1)
+    monkeypatch.setenv('TDG_PATCH_BM', '128')     # the 128-row tile (two images of 8 x 8 outputs, eight of 4 x 4)
+    test_conv_fwd_bwd(case, 1)
+    monkeypatch.delenv('TDG_PATCH_BM')
     n, h, w, cin, cout, k, s = case
     dev = torch.device('cuda:0')
     oh, pt, _ = T.same_pad(h, k, s)

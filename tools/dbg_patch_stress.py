@@ -37,6 +37,8 @@ def run(n, h, w, cin, cout, k, s, reps):
                 bad = ((ref - cur).abs() > 0).reshape(shape)
                 idx = bad.nonzero()
                 ch = torch.unique(idx[:, 3])
+                fi = bad.reshape(-1).nonzero()[:4, 0]
+                print('   values first-run / this-run:', [(float(ref[i]), float(cur[i])) for i in fi.tolist()])
                 print(name, 'rep', r, 'differs:', int(bad.sum()), 'elements; images', torch.unique(idx[:, 0]).tolist()[:30], 'rows', torch.unique(idx[:, 1]).tolist(),
                       'cols', torch.unique(idx[:, 2]).tolist(), 'channels', len(ch), int(ch.min()), int(ch.max()), flush=True)
         print(name, 'reps', reps, 'differing runs', nbad, flush=True)
