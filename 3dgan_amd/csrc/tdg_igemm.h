@@ -28,7 +28,7 @@ struct IgClass {
   // (a + dhq, b + dwq) of a [QH, QW] lattice per image, dhq = (dh - ph) / sigma
   int ngroups, QH, QW;
   FastDiv fd_qhw, fd_qw;   // divide by QH * QW, by QW
-  struct { short t0, nt, ph, pw; } grp[4];
+  struct { int t0, nt, ph, pw; } grp[4];   // (ints: the kernel reads them with scalar dword loads)
 };
 
 struct IgArgs {

@@ -1139,38 +1139,41 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
 // half's A fragments fa1 requested behind the first tiles.  Second half (after the step's "data ready" barrier): the NEXT
 // step's fa0 are requested into the registers the first half has finished with, and the last two tiles request the next
 // step's B fragments 0 and 1 from the next ring stage.  fb is indexed by tile; fb[2 TN], fb[2 TN + 1] carry over.
-template <int TM, int TN, int t>
+template <int TM, int TN, int ABL, int t>
 __device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (&fa0)[TM], bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
                                             const char* smem, const int (&a1)[TM], const char* pB, int coff0, int coff1) {
   if constexpr (t < TN) {
     constexpr int t2 = t + 2, ks2 = t2 / TN, j2 = t2 - ks2 * TN;
-    fb[t2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
-    if constexpr (t < TM) fa1[t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
+    if constexpr (ABL != 1) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
+    else fb[t2] = fb[t2 & 1];
+    if constexpr (t < TM && ABL != 2) fa1[t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][t], fb[t], fa0[i]);
     __builtin_amdgcn_sched_group_barrier(0x100, 1 + (t < TM ? 1 : 0), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-    patch_half0<TM, TN, t + 1>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
+    patch_half0<TM, TN, ABL, t + 1>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
   }
 }
-template <int TM, int TN, int t>
+template <int TM, int TN, int ABL, int t>
 __device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[TM], const bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
                                             const char* smem, const int (&a0n)[TM], const char* pB, const char* pBn, int coff0, int coff1) {
   constexpr int NT = 2 * TN;
   if constexpr (t < NT) {
     constexpr int j = t - TN, t2 = t + 2;
-    if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
+    if constexpr (ABL == 1) fb[t2] = fb[t2 & 1];
+    else if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
     else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's tiles 0 and 1
-    if constexpr (j >= 1 && j <= TM) fa0[j - 1] = *reinterpret_cast<const bf16x8*>(smem + a0n[j - 1]);   // (tile TN no longer reads fa0)
+    if constexpr (j >= 1 && j <= TM && ABL != 2) fa0[j - 1] = *reinterpret_cast<const bf16x8*>(smem + a0n[j - 1]);   // (tile TN no longer reads fa0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa1[i]);
     __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((j >= 1 && j <= TM) ? 1 : 0), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
-    patch_half1<TM, TN, t + 1>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
+    patch_half1<TM, TN, ABL, t + 1>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
   }
 }
 
-template <int BM, int BN, int PF>
+// ABL (diagnostic instantiations, TDG_PATCH_ABL): 1 = no B fragment reads in the loop, 2 = no A fragment reads, 3 = no address arithmetic
+template <int BM, int BN, int ABL>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs args) {
   using T = bf16_t;
   constexpr int NTHR = 512, CW = 4, LW = 4;
@@ -1212,46 +1215,70 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
   const int SLC = ntaps * PT_CK;                       // chunks per slice
   const int P = args.nslices * G;                      // phases
 
-  unsigned long long ph0 = 0, ph1 = 0, t0 = 0, t1 = 0, t2 = 0, s_issue = 0, s_mma = 0, s_sync = 0;   // stamps (diagnostic build only)
+  unsigned long long ph0 = 0, ph1 = 0, php = 0, t0 = 0, t1 = 0, t2 = 0, s_issue = 0, s_mma = 0, s_sync = 0;   // stamps (diagnostic build only)
+  unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   TDG_STAMP(ph0);
   // ---- tables: bias row, zero pixel, per-chunk A table ------------------------------------------------------------
   const float bias_v = (tid < BNL && args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
   if (tid < PT_ZEROB / 4) reinterpret_cast<int*>(smem + OFF_ZERO)[tid] = 0;
-  // lane t (< 32) holds tap t of the class: group, lattice offsets (+8, unsigned nibbles) -- read with lane crossbars below
-  // instead of per-entry kernel-argument loads
-  int tapvec;
-  {
-    const int t = lane & 31;
-    int gi = 0;
+  // lane t (< 32) holds tap t of the class: group, lattice offsets (+8, unsigned nibbles) -- read with lane crossbars below.
+  // Built from SCALAR loads of the class's tap table (they ride in the kernel-argument batch at kernel entry; a per-lane
+  // load of cl.tap[lane] was a cold vector-memory miss in front of everything the prologue does).  Compute waves only.
+  TDG_STAMP(q0);
+  int tapvec = 0;
+  if (is_mma) {
+    // every kernel-argument word first (two batches of scalar loads), then a fully unrolled loop over registers: a loop
+    // with a dependent scalar load per tap cost ~300 clocks per iteration
+    int tw[IG_MAX_TAPS / 2], g_t0[4], g_ph[4], g_pw[4];
+    const int sgs = args.sigma - 1;                      // log2(sigma)
 #pragma unroll
-    for (int k = 1; k < 4; ++k) gi += (k < G && t >= cl.grp[k].t0) ? 1 : 0;
-    const int pk = cl.tap[t];
-    const int dhq = (tap_dh(pk) - cl.grp[gi].ph) / args.sigma, dwq = (tap_dw(pk) - cl.grp[gi].pw) / args.sigma;   // exact by construction
-    tapvec = gi | ((dhq + 8) << 4) | ((dwq + 8) << 8);
-  }
-  // chunk table, two words per K chunk: the fragment's byte address minus the row's pixel offset (patch buffer, dq pixels,
-  // chunk j) and the tap's index = the bit of the row's validity mask to test (31: K padding, never set)
-  for (int g0 = 0; g0 < nsteps * 8; g0 += NTHR) {
-    const int g = g0 + tid;
-    const unsigned u = fd_div((unsigned)g, args.fd_ck);
-    const int j = g - (int)u * PT_CK;
-    const unsigned sl = fd_div(u, cl.fd_nt);
-    const int t = (int)(u - sl * (unsigned)ntaps);
-    const int tv = __builtin_amdgcn_ds_bpermute((t & 31) << 2, tapvec);
-    int w0 = 0, w1 = 31;
-    if ((int)sl < args.nslices) {
-      const int gi = tv & 15, dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
-      const int p = (int)sl * G + gi;
-      const int buf = p - (p / PT_NPB) * PT_NPB;
-      w0 = OFF_PATCH + buf * PT_PATCHB + (dhq * QW + dwq) * PT_PIXB + j * 16;
-      w1 = t;
+    for (int k = 0; k < IG_MAX_TAPS / 2; ++k) tw[k] = reinterpret_cast<const int*>(cl.tap)[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { g_t0[k] = cl.grp[k].t0; g_ph[k] = cl.grp[k].ph; g_pw[k] = cl.grp[k].pw; }
+    {
+      // lane t picks its own tap word out of the 16 scalar registers (a select chain: ~30 instructions; one pass over the
+      // taps with the lane as the loop variable was ~800)
+      const int t = lane & (IG_MAX_TAPS - 1);
+      int w = tw[0];
+#pragma unroll
+      for (int k = 1; k < IG_MAX_TAPS / 2; ++k) w = (t >> 1) == k ? tw[k] : w;
+      int gi = 0, ph = g_ph[0], pw = g_pw[0];
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const bool in = k < G && t >= g_t0[k];
+        gi = in ? k : gi; ph = in ? g_ph[k] : ph; pw = in ? g_pw[k] : pw;
+      }
+      const int pk = (t & 1) ? (w >> 16) : w;
+      const int dhq = (tap_dh(pk) - ph) >> sgs, dwq = (tap_dw(pk) - pw) >> sgs;          // exact multiples of sigma (1 or 2)
+      tapvec = gi | ((dhq + 8) << 4) | ((dwq + 8) << 8);
     }
-    if (g < nsteps * 8) {
-      sTab[2 * g] = w0;
-      sTab[2 * g + 1] = w1;
+    TDG_STAMP(q1);
+    // chunk table, two words per K chunk: the fragment's byte address minus the row's pixel offset (patch buffer, dq pixels,
+    // chunk j) and the tap's index = the bit of the row's validity mask to test (31: K padding, never set)
+    for (int g0 = 0; g0 < nsteps * 8; g0 += 64 * CW) {
+      const int g = g0 + tid;
+      const unsigned u = fd_div((unsigned)g, args.fd_ck);
+      const int j = g - (int)u * PT_CK;
+      const unsigned sl = fd_div(u, cl.fd_nt);
+      const int t = (int)(u - sl * (unsigned)ntaps);
+      const int tv = __builtin_amdgcn_ds_bpermute((t & 31) << 2, tapvec);
+      int w0 = 0, w1 = 31;
+      if ((int)sl < args.nslices) {
+        const int gi = tv & 15, dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
+        const int p = (int)sl * G + gi;
+        const int buf = p - (p / PT_NPB) * PT_NPB;
+        w0 = OFF_PATCH + buf * PT_PATCHB + (dhq * QW + dwq) * PT_PIXB + j * 16;
+        w1 = t;
+      }
+      if (g < nsteps * 8) {
+        sTab[2 * g] = w0;
+        sTab[2 * g + 1] = w1;
+      }
     }
   }
+  TDG_STAMP(q2);
   if (tid < BNL) sBias[tid] = bias_v;
+  TDG_STAMP(q3);
 
   const int r16 = lane & 15, q = lane >> 4;
   f32x4 acc[TM][TN];
@@ -1297,9 +1324,9 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     auto ph_end_chunk = [&](const Ph& x) { return x.sl * SLC + (cl.grp[x.gi].t0 + cl.grp[x.gi].nt) * PT_CK; };
     auto ph_delta = [&](const Ph& x) { return (unsigned)(((cl.grp[x.gi].ph * args.SW + cl.grp[x.gi].pw) * args.Cs + x.sl * PT_CK * 8) * 2); };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's table / zero-pixel stores are done before any LDS-DMA is pending
-    // ---- prologue: ring stages 0 and 1 first (their lane constants are cheap), then the first PT_NPB patches
+    // ---- prologue: ring stage 0 first (its lane constants are cheap), the first patch, then what step 0 does not read yet
+    // (patches 1 and 2, ring stage 1), which stays in flight across the prologue barrier: the wait of step 0 covers it
     b_pieces(0);
-    b_pieces(1);
     // patch pieces: piece ps * 4 + lwave of a patch, 64 consecutive 16-byte chunks of its [pixel][PT_CK] image
     const int IPT = BM / GHW;                          // images per row tile
     const int nimg = M / GHW;
@@ -1321,25 +1348,40 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(smem + OFF_PATCH + x.buf * PT_PATCHB + (ps * LW + lwave) * 1024), 16, off, 0, 0, 0);
     };
     Ph pn{0, 0, 0};
-    for (int p = 0; p < PT_NPB; ++p) {
-      if (p < P) {
-        const unsigned dl = ph_delta(pn);
-        a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
-        ph_next(pn);
-      }
+    {
+      const unsigned dl0 = ph_delta(pn);
+      a_piece(pn, dl0, IntC<0>{}); a_piece(pn, dl0, IntC<1>{}); a_piece(pn, dl0, IntC<2>{}); a_piece(pn, dl0, IntC<3>{});
+      ph_next(pn);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    b_pieces(1);
+    TDG_STAMP(t0);
+    s_mma = t0 - ph0;                                    // (stamps: kernel entry -> prologue pieces issued)
+    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // stage 0 and patch 0 have landed; stage 1 stays in flight
     __builtin_amdgcn_s_barrier();
-    Ph pf{0, 0, 0};                                      // the phase whose buffer pn takes over
-    int left = P - PT_NPB;                               // phases still to load
-    int ready = left > 0 ? (ph_end_chunk(pf) - 1) / 8 + 1 : (1 << 30);
+    TDG_STAMP(php);
+    // Patches 1 and 2 are loaded whole (4 pieces per wave) in steps 0 and 1 -- their buffers are free, and with every
+    // workgroup of a round in its prologue at once the first loads come from HBM at ~11 B/clk/CU: the prologue only waits for
+    // what step 0 reads.  From patch PT_NPB on: two pieces per step once the buffer's previous phase has been read.
+    Ph pf{0, 0, 0};                                      // the phase whose buffer pn takes over (from patch PT_NPB on)
+    int left = P - 1;                                    // phases still to load
+    int ready = P > PT_NPB ? (ph_end_chunk(pf) - 1) / 8 + 1 : (1 << 30);
+    if (ready < PT_NPB - 1) ready = PT_NPB - 1;          // (steps 0 .. PT_NPB - 2 carry the whole-patch loads)
     unsigned dl = left > 0 ? ph_delta(pn) : 0u;
     for (int step = 0; step < nsteps; ++step) {
       TDG_STAMP(t0);
       b_pieces(step + 2);
-      bool patch = true;
-      if (step == ready) {
+      int np = 7;                                        // pieces issued in this step
+      if (step < PT_NPB - 1) {
+        if (left > 0) {
+          a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
+          ph_next(pn);
+          --left;
+          dl = left > 0 ? ph_delta(pn) : 0u;
+          np = 11;
+        }
+      } else if (step == ready) {
         a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{});
+        np = 9;
       } else if (step == ready + 1) {
         a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
         ph_next(pn);
@@ -1347,13 +1389,13 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
         --left;
         ready = left > 0 ? max((ph_end_chunk(pf) - 1) / 8 + 1, step + 1) : (1 << 30);
         dl = left > 0 ? ph_delta(pn) : 0u;
-      } else {
-        patch = false;
+        np = 9;
       }
       TDG_STAMP(t1);
       // leave exactly this step's pieces in flight
       if (step == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (patch) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else if (np == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+      else if (np == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       __builtin_amdgcn_s_barrier();                        // A: every piece issued before this step has landed
       __builtin_amdgcn_s_barrier();                        // B: the compute waves are done with this step's stage
@@ -1364,22 +1406,38 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     // ================================ compute waves ================================
     // per row tile: the row's pixel offset inside a patch and a validity bit per tap (bit t: tap t reads inside the image)
     int base_i[TM], mask_i[TM];
+    {
+      int a_i[TM], b_i[TM];
+      unsigned rowbits[TM], colbits[TM];
+      bool ok_i[TM];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int loc = wave * WMR + i * 16 + r16;
-      const bool ok = m0 + loc < M;
-      const unsigned il = fd_div((unsigned)loc, cl.fd_ghw);
-      const int rem = loc - (int)il * GHW;
-      const int a = (int)fd_div((unsigned)rem, cl.fd_gw), b = rem - a * cl.GW;
-      base_i[i] = (((int)il * QH + a) * QW + b) * PT_PIXB;
-      int mk = 0;
-      for (int t = 0; t < ntaps; ++t) {
-        const int tv = __builtin_amdgcn_readlane(tapvec, t);
-        const int dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
-        const int v = (ok & ((unsigned)(a + dhq) < (unsigned)QH) & ((unsigned)(b + dwq) < (unsigned)QW)) ? 1 : 0;
-        mk |= v << t;
+      for (int i = 0; i < TM; ++i) {
+        const int loc = wave * WMR + i * 16 + r16;
+        ok_i[i] = m0 + loc < M;
+        const unsigned il = fd_div((unsigned)loc, cl.fd_ghw);
+        const int rem = loc - (int)il * GHW;
+        a_i[i] = (int)fd_div((unsigned)rem, cl.fd_gw);
+        b_i[i] = rem - a_i[i] * cl.GW;
+        base_i[i] = (((int)il * QH + a_i[i]) * QW + b_i[i]) * PT_PIXB;
+        rowbits[i] = colbits[i] = 0u;
       }
-      mask_i[i] = mk;
+      // validity mask = (taps whose row offset keeps the row inside the lattice) & (the same for columns): per distinct
+      // offset d one ballot over the tap lanes gives the set of taps with that offset (a loop over the taps cost ~3000 clocks)
+      const bool is_tap = lane < 32 && lane < ntaps;
+      const int my_dh = ((tapvec >> 4) & 15) - 8, my_dw = ((tapvec >> 8) & 15) - 8;
+      for (int d = -8; d < 8; ++d) {
+        const unsigned tr = (unsigned)__builtin_amdgcn_ballot_w64(is_tap && my_dh == d);
+        const unsigned tc = (unsigned)__builtin_amdgcn_ballot_w64(is_tap && my_dw == d);
+        if (tr | tc) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            rowbits[i] |= (unsigned)(a_i[i] + d) < (unsigned)QH ? tr : 0u;
+            colbits[i] |= (unsigned)(b_i[i] + d) < (unsigned)QW ? tc : 0u;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) mask_i[i] = ok_i[i] ? (int)(rowbits[i] & colbits[i]) : 0;
     }
     const int swl = (r16 >> 1) & 7;
     const int coff0 = ((0 * 4 + q) ^ swl) << 4, coff1 = ((1 * 4 + q) ^ swl) << 4;
@@ -1391,7 +1449,10 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     };
     const i32x2* sTab2 = reinterpret_cast<const i32x2*>(sTab);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    TDG_STAMP(t0);
+    s_issue = t0 - ph0;                                    // (stamps: kernel entry -> tables and masks built)
     __builtin_amdgcn_s_barrier();                          // tables, zero pixel, first patches, ring stage 0
+    TDG_STAMP(php);
     int a0[TM], a1[TM];
     a_offsets(sTab2[q], a0);
     a_offsets(sTab2[4 + q], a1);
@@ -1413,14 +1474,19 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       const char* pBn = smem + OFF_RING + stn * STAGE + r16 * IG_BKB;
       // the next step's fragment addresses (from the chunk words read a step ago) and the chunk words of the step after
       int a0n[TM], a1n[TM];
-      a_offsets(e0, a0n);
-      a_offsets(e1, a1n);
+      if constexpr (ABL == 3) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { a0n[i] = a0[i]; a1n[i] = a1[i]; }
+      } else {
+        a_offsets(e0, a0n);
+        a_offsets(e1, a1n);
+      }
       const int s2 = step + 2 < nsteps ? step + 2 : step;
       e0 = sTab2[s2 * 8 + q];
       e1 = sTab2[s2 * 8 + 4 + q];
-      patch_half0<TM, TN, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
+      patch_half0<TM, TN, ABL, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
       __builtin_amdgcn_s_barrier();                      // A: the loaders have seen step + 1's pieces land
-      patch_half1<TM, TN, TN>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
+      patch_half1<TM, TN, ABL, TN>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
       fb[0] = fb[2 * TN];
       fb[1] = fb[2 * TN + 1];
 #pragma unroll
@@ -1451,7 +1517,9 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     TDG_STAMP(ph3);
     if (lane == 0) {
       unsigned long long* o = args.stamps + 262144 + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
-      o[0] = ph0; o[1] = ph1; o[2] = ph1; o[3] = ph3;
+      o[0] = ph0; o[1] = php; o[2] = ph1; o[3] = ph3;       // entry, end of prologue, end of K loop, end of epilogue
+      unsigned long long* o2 = args.stamps + 524288 + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o2[0] = q0 - ph0; o2[1] = q1 - ph0; o2[2] = q2 - ph0; o2[3] = q3 - ph0;
     }
   }
 #endif
@@ -3013,7 +3081,7 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
       for (int g = 0; g < ng; ++g)
         if (c.grp[g].ph == ph && c.grp[g].pw == pw) return false;     // a group split in two: not the K order this kernel wants
       if (ng == 4) return false;
-      c.grp[ng].t0 = (short)t; c.grp[ng].nt = 1; c.grp[ng].ph = (short)ph; c.grp[ng].pw = (short)pw;
+      c.grp[ng].t0 = t; c.grp[ng].nt = 1; c.grp[ng].ph = ph; c.grp[ng].pw = pw;
       ++ng;
     }
     c.ngroups = ng; c.QH = QH; c.QW = QW;
@@ -3022,7 +3090,10 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
     const int P = a.nslices * ng, slc = c.ntaps * PT_CK;
     auto first_chunk = [&](int p) { return (p / ng) * slc + c.grp[p % ng].t0 * PT_CK; };
     auto end_chunk = [&](int p) { return (p / ng) * slc + (c.grp[p % ng].t0 + c.grp[p % ng].nt) * PT_CK; };
-    int prev_issue = -2;
+    // patches 1 .. PT_NPB - 1 go out whole in steps 0 .. PT_NPB - 2 (visible to the reads of step issue + 2)
+    for (int p = 1; p < PT_NPB && p < P; ++p)
+      if (first_chunk(p) / 8 < (p - 1) + 2) return false;
+    int prev_issue = PT_NPB - 3;                             // (the first two-step load starts at step PT_NPB - 1 at the earliest)
     for (int p = PT_NPB; p < P; ++p) {
       const int ready = (end_chunk(p - PT_NPB) - 1) / 8 + 1;
       const int issue = ready > prev_issue + 2 ? ready : prev_issue + 2;
@@ -3056,7 +3127,12 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   const size_t lds = PT_ZEROB + 3 * (size_t)BNL * IG_BKB + PT_NPB * PT_PATCHB + (size_t)smax * 64 + BNL * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (BM == 192) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     attr_set = true;
   }
   static char name[64] = "";
@@ -3064,7 +3140,15 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   tdg_note_kernel(name);
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
   tdg_timing_start(name, t_flops, s);
-  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 2>), grid, block, lds, s, a);
+  const int abl = (BM == 192 && getenv("TDG_PATCH_ABL")) ? atoi(getenv("TDG_PATCH_ABL")) : 0;     // diagnostics (results are garbage)
+  if constexpr (BM == 192) {
+    if (abl == 1) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 1>), grid, block, lds, s, a);
+    else if (abl == 2) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 2>), grid, block, lds, s, a);
+    else if (abl == 3) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 3>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
+  } else {
+    hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
+  }
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_patch");
   return TDG_OK;
