@@ -5,6 +5,7 @@
 #include <stdarg.h>
 
 #include "tdg_common.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------- error state
 static thread_local char g_err[512] = "";
@@ -245,7 +246,11 @@ __device__ __forceinline__ void load_vw(const T* p, float (&v)[VW]) {
 
 template <typename T, int MODE, int VW>
 __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const ColArgs a) {
-  __shared__ float sh[2][VW][256];
+  // f32 tensors (the parity path) are summed in f64: with 32768-row columns whose terms cancel to ~1e-3 of their size (the
+  // batch-norm backward sums of the generator at batch 512) f32 running sums were what kept the gradients off the
+  // float64 oracle by 2-3e-3; bf16 tensors (the throughput path) keep f32 sums
+  using Acc = typename std::conditional<sizeof(T) == 4, double, float>::type;
+  __shared__ Acc sh[2][VW][256];
   const int CL = g.CL, RL = 256 / CL;
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int r0 = blockIdx.x * g.rows_per_blk;
@@ -253,9 +258,9 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
   const T* x = static_cast<const T*>(a.x);
   const T* y = static_cast<const T*>(a.y);
   const int c = (blockIdx.y * CL + tx) * VW;
-  float s0[VW], s1[VW];
+  Acc s0[VW], s1[VW];
 #pragma unroll
-  for (int e = 0; e < VW; ++e) s0[e] = s1[e] = 0.f;
+  for (int e = 0; e < VW; ++e) s0[e] = s1[e] = 0;
   if (c < g.C) {
     float pivot[VW], bta[VW];
 #pragma unroll
@@ -309,10 +314,10 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
   if (ty == 0 && c < g.C) {
 #pragma unroll
     for (int e = 0; e < VW; ++e) {
-      float t0 = 0.f, t1 = 0.f;
+      Acc t0 = 0, t1 = 0;
       for (int k = 0; k < RL; ++k) { t0 += sh[0][e][k * CL + tx]; t1 += sh[1][e][k * CL + tx]; }
-      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c + e] = t0;
-      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c + e] = t1;
+      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c + e] = (float)t0;
+      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c + e] = (float)t1;
     }
   }
 }
@@ -335,10 +340,11 @@ struct FinArgs {
 template <typename T, int MODE, int CH>
 __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   constexpr int RL = 256 / CH;
-  __shared__ float sh[2][RL][CH];
+  using Acc = typename std::conditional<sizeof(T) == 4, double, float>::type;     // (see col_partial_kernel)
+  __shared__ Acc sh[2][RL][CH];
   const int tx = threadIdx.x & (CH - 1), ty = threadIdx.x / CH;
   const int c = blockIdx.x * CH + tx;
-  float s0 = 0.f, s1 = 0.f;
+  Acc s0 = 0, s1 = 0;
   if (c < a.C)
     for (int b0 = ty; b0 < a.nblk; b0 += 4 * RL) {
       float p0[4], p1[4];
@@ -356,25 +362,25 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   sh[1][ty][tx] = s1;
   __syncthreads();
   if (ty != 0 || c >= a.C) return;
-  s0 = s1 = 0.f;
+  s0 = s1 = 0;
 #pragma unroll
   for (int k = 0; k < RL; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
-  const float inv = 1.f / (float)a.rows;
+  const Acc inv = (Acc)1 / (Acc)a.rows;
   if (MODE == FIN_BN_STATS) {
     const float pivot = a.pivot_f ? a.pivot_f[c] : (a.x0 ? to_f32<T>(static_cast<const T*>(a.x0)[c]) : 0.f);
-    const float md = s0 * inv;
-    const float var = fmaxf(s1 * inv - md * md, 0.f);
-    a.out0[c] = pivot + md;
-    a.out0[a.C + c] = rsqrtf(var + a.eps);
+    const Acc md = s0 * inv;
+    const Acc var = s1 * inv - md * md > 0 ? s1 * inv - md * md : 0;
+    a.out0[c] = (float)(pivot + md);
+    a.out0[a.C + c] = (float)(1.0 / sqrt((double)var + (double)a.eps));
   } else if (MODE == FIN_BN_BWD) {
-    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
-    a.out1[c] = s0 * inv;
-    a.out1[a.C + c] = s1 * inv;
+    a.out0[c] = (float)((a.beta_acc != 0.f ? (Acc)a.beta_acc * a.out0[c] : 0) + s0);
+    a.out1[c] = (float)(s0 * inv);
+    a.out1[a.C + c] = (float)(s1 * inv);
   } else if (MODE == FIN_ACC2) {
-    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
-    a.out1[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out1[c] : 0.f) + s1;
+    a.out0[c] = (float)((a.beta_acc != 0.f ? (Acc)a.beta_acc * a.out0[c] : 0) + s0);
+    a.out1[c] = (float)((a.beta_acc != 0.f ? (Acc)a.beta_acc * a.out1[c] : 0) + s1);
   } else {
-    a.out0[c] = (a.beta_acc != 0.f ? a.beta_acc * a.out0[c] : 0.f) + s0;
+    a.out0[c] = (float)((a.beta_acc != 0.f ? (Acc)a.beta_acc * a.out0[c] : 0) + s0);
   }
 }
 template <typename T, int MODE>
