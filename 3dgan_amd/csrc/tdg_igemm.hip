@@ -1367,21 +1367,25 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     int ready = P > PT_NPB ? (ph_end_chunk(pf) - 1) / 8 + 1 : (1 << 30);
     if (ready < PT_NPB - 1) ready = PT_NPB - 1;          // (steps 0 .. PT_NPB - 2 carry the whole-patch loads)
     unsigned dl = left > 0 ? ph_delta(pn) : 0u;
+    // ONE barrier per K step, in the middle of the compute waves' step (between its two 32-deep halves): behind barrier M(s)
+    // the loaders overwrite ring stage s + 2 (= s - 1: read for the last time before M(s)) and wait for those pieces to land
+    // before M(s + 1), behind which the compute waves start reading them.  A loader has a whole step for ~550 clocks of issue
+    // and the load latency; the compute waves never wait for a second barrier.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // ring stage 1 (requested in the prologue)
     for (int step = 0; step < nsteps; ++step) {
       TDG_STAMP(t0);
+      __builtin_amdgcn_s_barrier();                        // M(step)
+      TDG_STAMP(t1);
       b_pieces(step + 2);
-      int np = 7;                                        // pieces issued in this step
       if (step < PT_NPB - 1) {
         if (left > 0) {
           a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
           ph_next(pn);
           --left;
           dl = left > 0 ? ph_delta(pn) : 0u;
-          np = 11;
         }
       } else if (step == ready) {
         a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{});
-        np = 9;
       } else if (step == ready + 1) {
         a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
         ph_next(pn);
@@ -1389,19 +1393,12 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
         --left;
         ready = left > 0 ? max((ph_end_chunk(pf) - 1) / 8 + 1, step + 1) : (1 << 30);
         dl = left > 0 ? ph_delta(pn) : 0u;
-        np = 9;
       }
-      TDG_STAMP(t1);
-      // leave exactly this step's pieces in flight
-      if (step == nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (np == 11) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-      else if (np == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // A: every piece issued before this step has landed
-      __builtin_amdgcn_s_barrier();                        // B: the compute waves are done with this step's stage
       TDG_STAMP(t2);
-      s_issue += t1 - t0; s_sync += t2 - t1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_sync += t1 - t0; s_issue += t2 - t1;
     }
+    __builtin_amdgcn_s_barrier();                          // F: the compute waves are done with ring and patches
   } else {
     // ================================ compute waves ================================
     // per row tile: the row's pixel offset inside a patch and a validity bit per tap (bit t: tap t reads inside the image)
@@ -1485,19 +1482,19 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       e0 = sTab2[s2 * 8 + q];
       e1 = sTab2[s2 * 8 + 4 + q];
       patch_half0<TM, TN, ABL, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
-      __builtin_amdgcn_s_barrier();                      // A: the loaders have seen step + 1's pieces land
+      TDG_STAMP(t1);
+      __builtin_amdgcn_s_barrier();                      // M(step): the pieces of ring stage step + 1 and of the patches behind it have landed
+      TDG_STAMP(t2);
       patch_half1<TM, TN, ABL, TN>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
       fb[0] = fb[2 * TN];
       fb[1] = fb[2 * TN + 1];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a1[i] = a1n[i];
       st = stn;
-      TDG_STAMP(t1);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                      // B: this stage and the patches read in this step may be overwritten
-      TDG_STAMP(t2);
-      s_mma += t1 - t0; s_sync += t2 - t1;
+      s_sync += t2 - t1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // F: every wave has read its last fragments (the epilogue stages over ring and patches)
   }
   TDG_STAMP(ph1);
 #ifdef TDG_STAMPS

@@ -139,6 +139,23 @@ def newest_pmc_file():
     return os.path.join(d, names[-1]) if names else None
 
 
+def _kernel_key(name):
+    """(base name, leading integer template arguments) of a kernel name in any of the spellings that meet here: the
+    library's own ("igemm_fwd_patch_kernel<bf16,192,208>"), rocprofv3's mangled ("_Z22igemm_fwd_patch_kernelILi192ELi208ELi0EEv6IgArgs")
+    or demangled ("void igemm_fwd_patch_kernel<192, 208, 0>(IgArgs)") form.  The dtype token is dropped."""
+    import re
+    name = name.strip()
+    if name.startswith('_Z'):
+        m = re.match(r'_Z\d+([A-Za-z_0-9]+?)I(.*)', name)
+        if not m:
+            return name, []
+        return m.group(1), [int(v) for v in re.findall(r'Li(\d+)E', m.group(2))]
+    name = re.sub(r'^void\s+', '', name)
+    base = name.split('<')[0].split('(')[0].strip()
+    args = name[name.index('<') + 1:name.rindex('>')] if '<' in name and '>' in name else ''
+    return base, [int(t.strip()) for t in args.split(',') if t.strip().isdigit()]
+
+
 def pmc_traffic(symbol):
     """HBM-side bytes per launch of the kernel `symbol` from the committed rocprofv3 PMC passes (FETCH_SIZE and
     WRITE_SIZE in separate runs of this same bench, KB per dispatch averaged over the kernel's launches), with the
@@ -150,13 +167,12 @@ def pmc_traffic(symbol):
             pmc = json.load(f)
     except (OSError, TypeError):
         return None, None
-    base = symbol.split('<')[0]
-    parts = symbol[symbol.index('<') + 1:-1].split(',') if '<' in symbol else []
-    want = base + 'I' + ('DF16b' if parts and parts[0] == 'bf16' else 'f') + ''.join('Li%sE' % v for v in parts[1:])
+    want = _kernel_key(symbol)
 
     def find(name):
         for k, v in pmc.get(name, {}).items():
-            if want in k:
+            have = _kernel_key(k)
+            if have[0] == want[0] and (have[1][:len(want[1])] == want[1] or (have[1] and want[1][-len(have[1]):] == have[1])):
                 return v['avg']
         return None
     fetch, write = find('FETCH_SIZE'), find('WRITE_SIZE')
