@@ -17,6 +17,16 @@ Follows (relative to /root/reference):
 
 This is what SURVEY section 4 names as the oracle of a multi-rank run: "n independent replicas, then mean" (batch
 norm and the penalty norm are per tower, so it is NOT one replica on the concatenated batch).
+
+`follow` (every step method): a free-running comparison over several optimizer steps is ill-conditioned however exact
+either side is -- Adam / RMSProp move a variable whose gradient is rounding residue by +-lr whatever its size, the two
+runs' variables part by ~lr in those elements, and a later step whose (l)relu masks or penalty norm sit close to a kink
+answers with 1e-3-sized gradient differences (this file's own float32 run leaves its float64 run by 4.8e-3 on
+discriminator/vars/c3/weights at the eighth optimizer step of tests/test_gpu_distributed.py's iwgan schedule).  A caller
+that holds the compared run's mean gradients of the step passes them as `follow`: the oracle still computes and records
+ITS tower mean at its current variables (`last_*_grads`, what the caller compares), but the optimizer step is taken with
+the followed gradients, so the oracle's variables stay within optimizer rounding of the compared run's and every step is
+a same-state comparison.
 """
 import numpy as np
 
@@ -36,12 +46,12 @@ class GanTowers:
     def rescale(x01):
         return 2.0 * (x01.reshape(x01.shape[0], -1) - 0.5)                           # models/gan.py:49-50
 
-    def d_step(self, xs, zs, alphas):
+    def d_step(self, xs, zs, alphas, follow=None):
         tower = [G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg)[1] for x, z, a in zip(xs, zs, alphas)]
         self.last_d_grads = T.average_gradients(tower)                               # models/gan.py:77
-        self.d_opt.apply(self.P, self.last_d_grads)                                  # :81
+        self.d_opt.apply(self.P, follow if follow is not None else self.last_d_grads)    # :81
 
-    def g_step(self, xs, zs, alphas):
+    def g_step(self, xs, zs, alphas, follow=None):
         """[g_train_op, losses] (models/gan.py:172): the losses are those of the LAST tower's batch, on the
         variables before this step's update."""
         tower, rep = [], None
@@ -51,7 +61,7 @@ class GanTowers:
             tower.append(gg)
             rep = {'g_loss': float(gl), 'd_loss': float(dl)}
         self.last_g_grads = T.average_gradients(tower)                               # :76
-        self.g_opt.apply(self.P, self.last_g_grads)                                  # :80
+        self.g_opt.apply(self.P, follow if follow is not None else self.last_g_grads)    # :80
         return rep
 
     def gan_step(self, xs, zs):
@@ -77,14 +87,14 @@ class VaeTowers:
         self.V, self.P, self.opt = V, P, T.init_optimizer(args)
         self.last_grads = None
 
-    def step(self, xs, epss):
+    def step(self, xs, epss, follow=None):
         tower, rep = [], None
         for x, e in zip(xs, epss):
             losses, c = self.V.forward(self.P, x, e)
             tower.append(self.V.backward(self.P, c))
             rep = {k: float(v) for k, v in losses.items()}
         self.last_grads = T.average_gradients(tower)
-        self.opt.apply(self.P, self.last_grads)
+        self.opt.apply(self.P, follow if follow is not None else self.last_grads)
         return rep
 
 
@@ -101,21 +111,21 @@ class Pix2pixTowers:
     def _mean(self, tower):
         return {k: sum(t[k] for t in tower) / len(tower) for k in tower[0]}
 
-    def d_step(self, pairs):
+    def d_step(self, pairs, follow=None):
         tower = []
         for x01, y01 in pairs:
             _, d_total, _ = self.PR.losses(self.P, x01, y01, self.args)
             tower.append(self.TR.grads_of(d_total, self.P, 'discriminator/'))
         self.last_d_grads = self._mean(tower)
-        self.d_opt.apply(self.P, self.last_d_grads)
+        self.d_opt.apply(self.P, follow if follow is not None else self.last_d_grads)
 
-    def g_step(self, pairs):
+    def g_step(self, pairs, follow=None):
         tower = []
         for x01, y01 in pairs:
             g_total, _, _ = self.PR.losses(self.P, x01, y01, self.args)
             tower.append(self.TR.grads_of(g_total, self.P, 'generator/'))
         self.last_g_grads = self._mean(tower)
-        self.g_opt.apply(self.P, self.last_g_grads)
+        self.g_opt.apply(self.P, follow if follow is not None else self.last_g_grads)
 
     def report(self, pairs):
         import torch

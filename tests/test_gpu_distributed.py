@@ -80,12 +80,29 @@ def _rel_l2(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()) / (np.linalg.norm(np.asarray(b, np.float64).ravel()) + 1e-30))
 
 
-def _oracle_towers(model, init, world=2):
-    """The float64 oracle of the staged run: (final variables, [mean gradients of optimizer step 0, 1, ...], losses per iteration)."""
+def _frac_beyond(a, b, tol):
+    """Share of the entries of `a` that lie further than tol * max|b| from `b`."""
+    b = np.asarray(b, np.float64)
+    return float((np.abs(np.asarray(a, np.float64) - b) > tol * (np.abs(b).max() + 1e-30)).mean())
+
+
+def _oracle_towers(model, init, hip_grads=None, world=2):
+    """The float64 oracle of the staged run: (final variables, [mean gradients of optimizer step 0, 1, ...], losses per iteration).
+    `hip_grads(i)` (the HIP run's all-reduced mean gradients of optimizer step i): the oracle FOLLOWS the HIP run -- it
+    records its own tower mean at its current variables, then takes the optimizer step with the HIP run's gradients, so
+    every step is compared at the same variables (oracle/towers_ref.py header: why a free run is ill-conditioned)."""
     from oracle import towers_ref as TW
     args = TI.make_args(model, world)
     P = {k: np.asarray(v, np.float64) for k, v in init.items()}
     step = [0]
+    nopt = [0]
+
+    def follow(conv=lambda a: a):
+        if hip_grads is None:
+            return None
+        g = {k: conv(np.asarray(v, np.float64)) for k, v in hip_grads(nopt[0]).items()}
+        nopt[0] += 1
+        return g
 
     def take(keys):
         out = [TI.step_inputs(model, r, step[0]) for r in range(world)]
@@ -96,7 +113,7 @@ def _oracle_towers(model, init, world=2):
         tw = TW.VaeTowers(P, args)
         for _ in range(TI.iterations(model)):
             xs, es = take(['x', 'eps'])
-            losses.append(tw.step(xs, es))
+            losses.append(tw.step(xs, es, follow=follow()))
             steps.append(tw.last_grads)
         return tw.P, steps, losses
     if model == 'pix2pix':
@@ -107,9 +124,9 @@ def _oracle_towers(model, init, world=2):
         as_pairs = lambda xy: [(torch.tensor(x), torch.tensor(y)) for x, y in zip(*xy)]
         num = lambda d: {k: v.detach().numpy().copy() for k, v in d.items()}
         for _ in range(TI.iterations(model)):
-            tw.d_step(as_pairs(take(['x', 'y'])))
+            tw.d_step(as_pairs(take(['x', 'y'])), follow=follow(torch.tensor))
             steps.append(num(tw.last_d_grads))
-            tw.g_step(as_pairs(take(['x', 'y'])))
+            tw.g_step(as_pairs(take(['x', 'y'])), follow=follow(torch.tensor))
             steps.append(num(tw.last_g_grads))
             losses.append(tw.report(as_pairs(take(['x', 'y']))))
         return num(tw.P), steps, losses
@@ -119,9 +136,9 @@ def _oracle_towers(model, init, world=2):
     tw = TW.GanTowers(P, cfg, args)
     for _ in range(TI.iterations(model)):
         for _d in range(TI.N_DISC):
-            tw.d_step(*take(['x', 'z', 'alpha']))
+            tw.d_step(*take(['x', 'z', 'alpha']), follow=follow())
             steps.append(tw.last_d_grads)
-        losses.append(tw.g_step(*take(['x', 'z', 'alpha'])))
+        losses.append(tw.g_step(*take(['x', 'z', 'alpha']), follow=follow()))
         steps.append(tw.last_g_grads)
     return tw.P, steps, losses
 
@@ -143,11 +160,28 @@ def _cos(a, b):
 #   pix2pix       D step 0: 2.3e-3 (discriminator/vars/m1/bias); G step 0: 9.3e-3; second iteration 2.6e-2 / 0.39, cos 0.9928
 #                 (N(0, 0.02) weights, sixteen generator layers, batch norm over 2 x 2 x 1 values at the first decoder layer,
 #                 Adam's sign-like first steps: DESIGN.md section 7 "Parity notes for pix2pix")
+# Audit trail: after the packed filters went to slice-major K order (commit 4a9aa09: another float32 summation order) the
+# FREE-running iwgan comparison turned red at the north-star's bound -- steps 4 and 7 at 2.6e-3 / 6.0e-3 (c2 weights / bias),
+# every other step <= 3e-5, identical on two boxes (gpurun_out/r3c_tests.log, r3d_iwgan2.log).  The oracle's own float32 run
+# parts from its float64 run the same way (4.8e-3 on c3/weights at step 7, 1e-6 elsewhere): Adam moves rounding-residue
+# gradients by +-lr, the variables part by ~1e-4 in those elements and a step near a kink answers with 1e-3.
+# Following the HIP run alone does not restore 1e-3 either (the oracle's float32 run FOLLOWED by its float64 run keeps the 4.8e-3 at step
+# 7): that step has a c2 pre-activation of 7.6e-8 on the x_hat path -- an lrelu kink within float32 rounding -- and one flipped
+# mask changes the penalty's gradient broadly (every filter at ~1.2e-3 relative l2, 0.3 - 0.7 % of the entries beyond 1e-3 of
+# the maximum, the bias gradients -- first order only -- stay at 1e-6).  Some pre-activation lies within 2e-6 of zero in
+# nearly every step of this schedule, so which steps flip is the rounding order's luck.  What is asserted now:
+#   * the oracle FOLLOWS the HIP run (takes its optimizer steps with the HIP run's mean gradients, oracle/towers_ref.py
+#     `follow`), so a flip does not compound and every step is a same-state comparison;
+#   * steps from identical state (first critic / first generator step): 1e-3 of the maximum on every entry, as before;
+#   * later steps: at most KINK_FRAC of a tensor's entries beyond 1e-3 of its maximum (a dropped exchange or a wrong 1/n
+#     moves ALL of them), no entry beyond 2e-2, cosine >= 0.9999.
 # so vae / pix2pix assert the first step of each net against a bound near its measured value and the later steps in
 # direction only.  A dropped exchange is an O(1) error on the FIRST step already (tower gradients on different shards differ
 # by far more than 2e-2 of their max) and is caught bit-exactly by the shards-vs-towers rehearsal above.
-BOUNDS = {'iwgan': (1e-3, (1e-3, 0.999999)), 'wgan': (1e-3, (1e-3, 0.999999)),
-          'vae': (1e-3, (0.15, 0.9999)), 'pix2pix': (2e-2, (None, 0.98))}
+# (first-step bound, (later-step max bound, later-step cosine bound, bound that at most KINK_FRAC of a tensor's entries may exceed))
+BOUNDS = {'iwgan': (1e-3, (2e-2, 0.9999, 1e-3)), 'wgan': (1e-3, (2e-2, 0.9999, 1e-3)),
+          'vae': (1e-3, (0.15, 0.9999, None)), 'pix2pix': (2e-2, (None, 0.98, None))}
+KINK_FRAC = 0.02
 
 
 @pytest.mark.parametrize('model,port', [('iwgan', 29571), ('wgan', 29572), ('vae', 29573), ('pix2pix', 29574)])
@@ -158,24 +192,30 @@ def test_two_replicas_match_the_oracle_tower_mean_f32(tmp_path, model, port):
     util.py:118-147)."""
     out = _two_ranks(str(tmp_path / 'staged.npz'), model, 'staged', port)
     init = {k[5:].replace('.', '/'): out[k] for k in out.files if k.startswith('init.')}
-    P, steps, losses = _oracle_towers(model, init)
+
+    def hip_grads(i):
+        pre = 'grad.%d.' % i
+        return {k[len(pre):].replace('.', '/'): out[k] for k in out.files if k.startswith(pre)}
+    P, steps, losses = _oracle_towers(model, init, hip_grads)
     n_steps = len([k for k in out.files if k.startswith('nstep.')])
     assert n_steps == len(steps)
     table = []
     for i, ref in enumerate(steps):
-        worst_rel, worst_cos = (0.0, ''), (1.0, '')
+        worst_rel, worst_cos, worst_frac = (0.0, ''), (1.0, ''), (0.0, '')
         for n, g in ref.items():
             if _zero_gradient_variable(model, n):
                 continue
             got = out['grad.%d.%s' % (i, n.replace('/', '.'))]
             r, c = _rel(got, g), _cos(got, g)
             worst_rel, worst_cos = max(worst_rel, (r, n)), min(worst_cos, (c, n))
-        table.append((i, worst_rel, worst_cos))
-    print('\n'.join('%s step %d: worst rel %.2e (%s), worst cos %.6f (%s)' % (model, i, r[0], r[1], c[0], c[1]) for i, r, c in table))
-    first, (later_rel, later_cos) = BOUNDS[model]
+            worst_frac = max(worst_frac, (_frac_beyond(got, g, 1e-3), n))
+        table.append((i, worst_rel, worst_cos, worst_frac))
+    print('\n'.join('%s step %d: worst rel %.2e (%s), worst cos %.6f (%s), largest share of entries beyond 1e-3 of the max %.2e (%s)' %
+                    (model, i, r[0], r[1], c[0], c[1], f[0], f[1]) for i, r, c, f in table))
+    first, (later_rel, later_cos, later_bulk) = BOUNDS[model]
     per_iter = TI.steps_per_iteration(model) - (1 if model == 'pix2pix' else 0)        # (pix2pix's third pass is the report)
     identical_state = {0} if model in ('vae',) else {0, per_iter - 1}                    # first critic step, first generator step
-    for i, (r, rn), (c, cn) in table:
+    for i, (r, rn), (c, cn), (f, fn) in table:
         if i in identical_state:
             if first is not None:
                 assert r < first, (i, rn, r)
@@ -184,6 +224,8 @@ def test_two_replicas_match_the_oracle_tower_mean_f32(tmp_path, model, port):
                 assert r < later_rel, (i, rn, r)
             if later_cos is not None:
                 assert c > later_cos, (i, cn, c)
+            if later_bulk is not None:
+                assert f <= KINK_FRAC, (i, fn, f)
     # reported losses: the LAST tower's (util.py:187-193), every iteration
     for k in losses[0]:
         got = out['loss_' + k]

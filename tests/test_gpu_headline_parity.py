@@ -63,6 +63,8 @@ def direction_and_scale(a, b):
     norm ratio of 0.5 / 2 -- properties a loose relative-l2 bound on a badly conditioned tensor cannot hide."""
     a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
     na, nb = np.linalg.norm(a), np.linalg.norm(b)
+    if nb == 0.0:            # an exactly-zero gradient (the critic's fc2 bias: +1/R and -1/R per row pair): the other must be zero too
+        return (1.0, 1.0) if na == 0.0 else (0.0, float('inf'))
     return float(a @ b / (na * nb + 1e-300)), float(na / (nb + 1e-300))
 
 
