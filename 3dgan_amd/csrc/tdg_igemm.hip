@@ -1134,16 +1134,24 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
 }
 
 // One K step of a compute wave -- TM row tiles x TN column tiles x two 32-deep halves = 2 TN "tiles" of TM MFMAs -- as a
-// chain that never drains: B fragment t + 2 is requested before the MFMAs of tile t issue, and the chain runs ACROSS the
+// chain that never drains: B fragment t + PT_LA is requested before the MFMAs of tile t issue, and the chain runs ACROSS the
 // step boundary.  First half (tiles 0 .. TN-1, K chunks 0-3): A fragments fa0 (loaded during the previous step), second
 // half's A fragments fa1 requested behind the first tiles.  Second half (after the step's "data ready" barrier): the NEXT
-// step's fa0 are requested into the registers the first half has finished with, and the last two tiles request the next
-// step's B fragments 0 and 1 from the next ring stage.  fb is indexed by tile; fb[2 TN], fb[2 TN + 1] carry over.
+// step's fa0 are requested into the registers the first half has finished with, and the last PT_LA tiles request the next
+// step's first B fragments from the next ring stage.  fb is indexed by tile; fb[2 TN ..] carry over.
+// The sched_group_barrier pipeline (DS reads of a tile, then its MFMAs) hands out DS instructions in program order, so
+// EVERY DS read of the loop body must have a slot: the chunk-table read in front of the first half has a group of its own
+// (without it the table read took fb's slot and every later fragment moved one group back: 48 clocks from request to use
+// instead of 96).  Measured with the slots right and PT_LA = 2, 3, 4 on one box: no change in time -- the step is not
+// bound by fragment latency; see DESIGN.md section 4, "What the patch kernel is bound by" (power, not cycles).
+#ifndef PT_LA
+#define PT_LA 3                        // B fragments requested this many tiles ahead of their MFMAs
+#endif
 template <int TM, int TN, int ABL, int t>
-__device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (&fa0)[TM], bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
+__device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (&fa0)[TM], bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + PT_LA],
                                             const char* smem, const int (&a1)[TM], const char* pB, int coff0, int coff1) {
   if constexpr (t < TN) {
-    constexpr int t2 = t + 2, ks2 = t2 / TN, j2 = t2 - ks2 * TN;
+    constexpr int t2 = t + PT_LA, ks2 = t2 / TN, j2 = t2 - ks2 * TN;
     if constexpr (ABL != 1) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
     else fb[t2] = fb[t2 & 1];
     if constexpr (t < TM && ABL != 2) fa1[t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
@@ -1155,14 +1163,14 @@ __device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (
   }
 }
 template <int TM, int TN, int ABL, int t>
-__device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[TM], const bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + 2],
+__device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[TM], const bf16x8 (&fa1)[TM], bf16x8 (&fb)[2 * TN + PT_LA],
                                             const char* smem, const int (&a0n)[TM], const char* pB, const char* pBn, int coff0, int coff1) {
   constexpr int NT = 2 * TN;
   if constexpr (t < NT) {
-    constexpr int j = t - TN, t2 = t + 2;
+    constexpr int j = t - TN, t2 = t + PT_LA;
     if constexpr (ABL == 1) fb[t2] = fb[t2 & 1];
     else if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
-    else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's tiles 0 and 1
+    else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's first tiles
     if constexpr (j >= 1 && j <= TM && ABL != 2) fa0[j - 1] = *reinterpret_cast<const bf16x8*>(smem + a0n[j - 1]);   // (tile TN no longer reads fa0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa1[i]);
@@ -1172,7 +1180,8 @@ __device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[
   }
 }
 
-// ABL (diagnostic instantiations, TDG_PATCH_ABL): 1 = no B fragment reads in the loop, 2 = no A fragment reads, 3 = no address arithmetic
+// ABL (diagnostic instantiations, TDG_PATCH_ABL): 1 = no B fragment reads in the loop, 2 = no A fragment reads, 3 = no address arithmetic,
+// 4 = no LDS-DMA pieces in the loop
 template <int BM, int BN, int ABL>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs args) {
   using T = bf16_t;
@@ -1376,8 +1385,9 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       TDG_STAMP(t0);
       __builtin_amdgcn_s_barrier();                        // M(step)
       TDG_STAMP(t1);
-      b_pieces(step + 2);
-      if (step < PT_NPB - 1) {
+      if constexpr (ABL != 4) b_pieces(step + 2);
+      if constexpr (ABL == 4) {
+      } else if (step < PT_NPB - 1) {
         if (left > 0) {
           a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
           ph_next(pn);
@@ -1455,13 +1465,13 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     a_offsets(sTab2[4 + q], a1);
     i32x2 e0 = sTab2[(nsteps > 1 ? 8 : 0) + q], e1 = sTab2[(nsteps > 1 ? 8 : 0) + 4 + q];     // step 1's chunks
     bf16x8 fa0[TM], fa1[TM];
-    bf16x8 fb[2 * TN + 2];
+    bf16x8 fb[2 * TN + PT_LA];
     {
       const char* pB = smem + OFF_RING + r16 * IG_BKB;
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(smem + a0[i]);
-      fb[0] = *reinterpret_cast<const bf16x8*>(pB + coff0);
-      fb[1] = *reinterpret_cast<const bf16x8*>(pB + 16 * IG_BKB + coff0);
+#pragma unroll
+      for (int k = 0; k < PT_LA; ++k) fb[k] = *reinterpret_cast<const bf16x8*>(pB + k * 16 * IG_BKB + coff0);
     }
     int st = 0;
     for (int step = 0; step < nsteps; ++step) {
@@ -1481,13 +1491,14 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       const int s2 = step + 2 < nsteps ? step + 2 : step;
       e0 = sTab2[s2 * 8 + q];
       e1 = sTab2[s2 * 8 + 4 + q];
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the chunk-table read (one ds_read2_b64): see patch_half0
       patch_half0<TM, TN, ABL, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
       TDG_STAMP(t1);
       __builtin_amdgcn_s_barrier();                      // M(step): the pieces of ring stage step + 1 and of the patches behind it have landed
       TDG_STAMP(t2);
       patch_half1<TM, TN, ABL, TN>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
-      fb[0] = fb[2 * TN];
-      fb[1] = fb[2 * TN + 1];
+#pragma unroll
+      for (int k = 0; k < PT_LA; ++k) fb[k] = fb[2 * TN + k];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a1[i] = a1n[i];
       st = stn;
@@ -3129,6 +3140,7 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     attr_set = true;
   }
@@ -3142,6 +3154,7 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
     if (abl == 1) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 1>), grid, block, lds, s, a);
     else if (abl == 2) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 2>), grid, block, lds, s, a);
     else if (abl == 3) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 3>), grid, block, lds, s, a);
+    else if (abl == 4) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 4>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
   } else {
     hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);

@@ -33,6 +33,8 @@ for wv, nm in ((0, 'compute wave 0'), (4, 'loader wave 4')):
 order = torch.argsort(ph[:, 0, 0])
 pro = (ph[:, 0, 1] - ph[:, 0, 0])[order]
 print('prologue of the first 256 workgroups %.0f, of the rest %.0f' % (pro[:256].mean(), pro[256:].mean() if pro.numel() > 256 else -1))
+for wv in range(8):
+    print('wave %d: barrier wait %.0f per step%s' % (wv, (st[:, wv, 2] / st[:, wv, 3]).mean(), '' if wv < 4 else ', piece issue %.0f per step' % (st[:, wv, 0] / st[:, wv, 3]).mean()))
 print('compute wave 0: entry -> tables built %.0f cycles; loader wave 4: entry -> prologue pieces issued %.0f cycles' % (st[:, 0, 0].mean(), st[:, 4, 1].mean()))
 qq = qq[:ph.shape[0]] if qq.shape[0] >= ph.shape[0] else qq
 m = qq[qq[:, 0, 3] > 0]
