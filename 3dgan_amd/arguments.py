@@ -26,26 +26,31 @@ class CustomArgumentParser(argparse.ArgumentParser):
     """hem/util/misc.py:72-82: `@file` lines are `key value value ...`; comments and blank lines are skipped."""
 
     def convert_arg_line_to_args(self, arg_line):
-        arg_line = arg_line.strip()
-        if len(arg_line) == 0 or arg_line[0] == '#':
+        words = arg_line.split()
+        if not words or words[0].startswith('#'):
             return []
-        kv = arg_line.split()
-        return ['--' + kv[0]] + kv[1:]
+        flag, values = words[0], words[1:]
+        return ['--' + flag, *values]
 
 
 class load_args_from_file(argparse.Action):
-    """train.py:25-37 (`--config FILE`): whitespace separated `key value` pairs; '--' is prefixed when missing;
-    values given on the command line win because only truthy parsed values are copied."""
+    """train.py:25-37 (`--config FILE`): the file is a flat stream of whitespace separated `key value` pairs (every even
+    token is a key and gets its `--` when it lacks one); the pairs are parsed by the same parser, and only what they set
+    to a truthy value is taken over, so a flag already given on the command line keeps its value unless the file names it too."""
 
     def __call__(self, parser, namespace, values, option_string=None):
-        contents = [t for line in values.read().splitlines() if not line.strip().startswith('#') for t in line.split()]
-        for i in range(int(len(contents) / 2)):
-            if contents[i * 2][0:2] != '--':
-                contents[i * 2] = '--' + contents[i * 2]
-        data, _ = parser.parse_known_args(contents, namespace=namespace)
-        for k, v in vars(data).items():
-            if v and k != option_string.strip('-'):
-                setattr(namespace, k, v)
+        tokens = []
+        for line in values.read().splitlines():
+            if not line.lstrip().startswith('#'):
+                tokens.extend(line.split())
+        for k in range(0, len(tokens) - len(tokens) % 2, 2):
+            if not tokens[k].startswith('--'):
+                tokens[k] = '--' + tokens[k]
+        own_dest = option_string.strip('-')
+        parsed, _unknown = parser.parse_known_args(tokens, namespace=namespace)
+        for dest, value in vars(parsed).items():
+            if dest != own_dest and value:
+                setattr(namespace, dest, value)
 
 
 def build_parser():

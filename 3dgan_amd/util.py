@@ -53,18 +53,19 @@ def collection_to_dict(collection):
 
 
 def format_for_terminal(results, prev_results):
-    """util.py:196-212 (including its first-call quirk of formatting in place)."""
+    """util.py:196-212: the tqdm postfix.  Without an earlier result every value becomes its '{:3f}' text -- IN the dict
+    that was passed in, as the reference does (its callers rely on nothing else reading it afterwards); with one, a new dict
+    with the value followed by the direction it moved in: (+), (-) or (~)."""
     if not prev_results:
-        disp_results = results
-        for k in disp_results:
-            disp_results[k] = '{:3f}'.format(disp_results[k])
-    else:
-        disp_results = {}
-        for k in prev_results:
-            diff = float(results[k]) - float(prev_results[k])
-            sym = '+' if diff > 0 else ('-' if diff < 0 else '~')
-            disp_results[k] = '{:3f}({})'.format(results[k], sym)
-    return disp_results
+        for key, value in list(results.items()):
+            results[key] = '{:3f}'.format(value)
+        return results
+    shown = {}
+    for key in prev_results:
+        change = float(results[key]) - float(prev_results[key])
+        mark = '~' if change == 0 else ('+' if change > 0 else '-')
+        shown[key] = '{:3f}({})'.format(results[key], mark)
+    return shown
 
 
 def chunks(x, n):
