@@ -1007,6 +1007,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
 #define PT_MAXPIX (PT_PATCHB / PT_PIXB)
 #define PT_APS 2                       // patch pieces per loader wave and K step
 #define PT_ZEROB 256                   // the zero pixel (LDS byte 0)
+// an A fragment by its LDS byte address (the dynamic LDS block of this kernel starts at LDS byte 0 -- it declares no static
+// LDS; the kernel checks -- so a table word IS the address: no per-read add of the block's base)
+__device__ __forceinline__ bf16x8 pt_lds_frag(int byte_addr) {
+  return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((__attribute__((address_space(3))) char*)nullptr + byte_addr);
+}
 
 // the bf16 epilogue of a BM x BN tile staged through LDS (shared with the forms of igemm_fwd_dma_kernel that inline it):
 // compute waves park bias + activation of their accumulators as bf16 rows, then every thread moves whole 16-byte
@@ -1144,6 +1149,9 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
 // (without it the table read took fb's slot and every later fragment moved one group back: 48 clocks from request to use
 // instead of 96).  Measured with the slots right and PT_LA = 2, 3, 4 on one box: no change in time -- the step is not
 // bound by fragment latency; see DESIGN.md section 4, "What the patch kernel is bound by" (power, not cycles).
+#ifndef PT_VBLOCK
+#define PT_VBLOCK 32
+#endif
 #ifndef PT_LA
 #define PT_LA 3                        // B fragments requested this many tiles ahead of their MFMAs
 #endif
@@ -1154,7 +1162,7 @@ __device__ __forceinline__ void patch_half0(f32x4 (&acc)[TM][TN], const bf16x8 (
     constexpr int t2 = t + PT_LA, ks2 = t2 / TN, j2 = t2 - ks2 * TN;
     if constexpr (ABL != 1) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + j2 * 16 * IG_BKB + (ks2 ? coff1 : coff0));
     else fb[t2] = fb[t2 & 1];
-    if constexpr (t < TM && ABL != 2) fa1[t] = *reinterpret_cast<const bf16x8*>(smem + a1[t]);
+    if constexpr (t < TM && ABL != 2) fa1[t] = pt_lds_frag(a1[t]);
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][t], fb[t], fa0[i]);
     __builtin_amdgcn_sched_group_barrier(0x100, 1 + (t < TM ? 1 : 0), 0);
@@ -1171,7 +1179,7 @@ __device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[
     if constexpr (ABL == 1) fb[t2] = fb[t2 & 1];
     else if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
     else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's first tiles
-    if constexpr (j >= 1 && j <= TM && ABL != 2) fa0[j - 1] = *reinterpret_cast<const bf16x8*>(smem + a0n[j - 1]);   // (tile TN no longer reads fa0)
+    if constexpr (j >= 1 && j <= TM && ABL != 2) fa0[j - 1] = pt_lds_frag(a0n[j - 1]);   // (tile TN no longer reads fa0)
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa1[i]);
     __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((j >= 1 && j <= TM) ? 1 : 0), 0);
@@ -1230,6 +1238,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
   // ---- tables: bias row, zero pixel, per-chunk A table ------------------------------------------------------------
   const float bias_v = (tid < BNL && args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
   if (tid < PT_ZEROB / 4) reinterpret_cast<int*>(smem + OFF_ZERO)[tid] = 0;
+  if ((unsigned)(size_t)(lds_ptr_t)smem != 0u) __builtin_trap();      // (pt_lds_frag: table words are absolute LDS addresses)
   // lane t (< 32) holds tap t of the class: group, lattice offsets (+8, unsigned nibbles) -- read with lane crossbars below.
   // Built from SCALAR loads of the class's tap table (they ride in the kernel-argument batch at kernel entry; a per-lane
   // load of cl.tap[lane] was a cold vector-memory miss in front of everything the prologue does).  Compute waves only.
@@ -1469,7 +1478,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     {
       const char* pB = smem + OFF_RING + r16 * IG_BKB;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa0[i] = *reinterpret_cast<const bf16x8*>(smem + a0[i]);
+      for (int i = 0; i < TM; ++i) fa0[i] = pt_lds_frag(a0[i]);
 #pragma unroll
       for (int k = 0; k < PT_LA; ++k) fb[k] = *reinterpret_cast<const bf16x8*>(pB + k * 16 * IG_BKB + coff0);
     }
@@ -1491,6 +1500,9 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       const int s2 = step + 2 < nsteps ? step + 2 : step;
       e0 = sTab2[s2 * 8 + q];
       e1 = sTab2[s2 * 8 + 4 + q];
+      // every vector instruction of the step in ONE block in front of the pipeline: vector instructions between the MFMA groups
+      // cost far more than in a block (measured both ways: DESIGN.md section 4)
+      __builtin_amdgcn_sched_group_barrier(0x002, PT_VBLOCK, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // the chunk-table read (one ds_read2_b64): see patch_half0
       patch_half0<TM, TN, ABL, 0>(acc, fa0, fa1, fb, smem, a1, pB, coff0, coff1);
       TDG_STAMP(t1);
