@@ -117,6 +117,8 @@ SIGNATURES = {
     'tdg_random_normal_dev': (_i, [_i, _u64, _u64, _vp, _sz, _vp, _vp]),
     'tdg_random_uniform_f32_dev': (_i, [_u64, _u64, _vp, _sz, _vp, _vp]),
     'tdg_png_unfilter': (_i, [C.c_char_p, _i, _i, _i, _vp]),
+    'tdg_jpeg_info': (_i, [C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'tdg_jpeg_decode': (_i, [C.c_char_p, _sz, _vp, _sz]),
 }
 
 _lib = None

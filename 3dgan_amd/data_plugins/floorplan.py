@@ -2,8 +2,9 @@
 `tf.train.Example` per image with the ENCODED file bytes under `image` (+ width / height / channels / filename),
 decoded, resized to 64 x 64 with TF-1.x bilinear `resize_images` and scaled to [0, 1].
 
-Supported encodings: PNG (3dgan_amd/png.py).  The reference calls `tf.image.decode_image`, which also takes JPEG / GIF /
-BMP; a record in one of those raises a ValueError naming the format (no JPEG decoder ships with this build).
+Supported encodings: JPEG (3dgan_amd/jpeg.py: baseline / extended-sequential files) and PNG (3dgan_amd/png.py).  The
+reference calls `tf.image.decode_image`, which also takes GIF / BMP and progressive JPEG; a record in one of those raises
+naming the format.
 Decoded images are cached as `<cache_dir>/floorplans.64.npy` when --cache_dir is given (`d.cache(...)`, data.py:51)."""
 import os
 
@@ -12,7 +13,7 @@ import torch
 
 from .DataPlugin import DataPlugin, find_file, dataset_dirs, write_cache_atomically
 from ._common import finish_images, resize_bilinear_tf1
-from .. import tfrecord, png
+from .. import tfrecord, png, jpeg
 
 
 class FloorplanDataset(DataPlugin):
@@ -38,7 +39,8 @@ class FloorplanDataset(DataPlugin):
         out = []
         for rec in tfrecord.read_records(tfr):
             ex = tfrecord.parse_example(rec)
-            img = png.decode(ex['image'], channels=3)                       # decode_image(channels=3), data.py:15
+            raw = ex['image']
+            img = jpeg.decode(raw) if jpeg.is_jpeg(raw) else png.decode(raw, channels=3)      # decode_image(channels=3), data.py:15
             x = torch.from_numpy(img.astype(np.float32))[None]
             x = resize_bilinear_tf1(x, 64, 64)                                # data.py:21
             out.append(np.clip(np.rint(x[0].numpy()), 0, 255).astype(np.uint8))

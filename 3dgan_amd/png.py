@@ -5,7 +5,7 @@ scanline reconstruction -- the only per-byte work -- is the native `tdg_png_unfi
 Supported: non-interlaced, bit depth 8 or 16, colour types 0 (grey), 2 (RGB), 4 (grey + alpha), 6 (RGBA): what the
 dataset converters write (`*_i.png` 8-bit RGB, `*_f.png` 16-bit grey depth, hem/data/nyuv2.py:128-131).  Palette images,
 1/2/4-bit depths and Adam7 interlacing raise ValueError; JPEG (the floorplan records are whatever the source files
-were: `decode_image`) is reported as such -- this build has no JPEG decoder.
+were: `decode_image`) is reported as such here -- 3dgan_amd/jpeg.py decodes those.
 """
 import struct
 import zlib

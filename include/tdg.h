@@ -354,6 +354,16 @@ int tdg_random_uniform_f32_dev(uint64_t seed, uint64_t stream_id, int32_t* draw_
  *      scanlines of 1 + row_bytes bytes, `out` receives rows * row_bytes bytes; bpp = bytes per complete pixel. */
 int tdg_png_unfilter(const unsigned char* filtered, int rows, int row_bytes, int bpp, unsigned char* out);
 
+/* ---- tdg_jpeg_info / tdg_jpeg_decode: a JPEG file's bytes -> width x height x 3 RGB bytes (host memory, no device work).
+ *      Replaces `tf.image.decode_image(..., channels=3)` on the reference's floorplan records, whose `image` feature is
+ *      the raw bytes of the source file (data/floorplan_tfrecords.py:26-41 writes them, data.py:15 decodes them).
+ *      Baseline and extended-sequential Huffman files, 8 bit, 1 (grayscale, replicated to 3 channels) or 3 components,
+ *      sampling factors 1 and 2, restart intervals; libjpeg's default arithmetic (accurate integer inverse DCT, triangle
+ *      chroma upsampling, 16-bit fixed-point YCbCr -> RGB).  Progressive / arithmetic / 12-bit / CMYK files: TDG_EINVAL
+ *      with the reason in tdg_last_error(). */
+int tdg_jpeg_info(const unsigned char* data, size_t nbytes, int* width, int* height, int* components);
+int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigned char* rgb, size_t rgb_bytes);
+
 #ifdef __cplusplus
 }
 #endif
