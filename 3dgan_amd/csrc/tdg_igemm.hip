@@ -992,9 +992,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
 //
 // 8 waves: 4 compute (48 rows x all 208 columns each, as igemm_fwd_dma_kernel's wave-specialised form) + 4 loaders.
 // Per K step a loader wave issues the 7 filter pieces of step s + 2 into the 3-stage ring and, in the two steps in which a
-// patch is loaded, PT_APS = 2 patch pieces; it waits with a counted vmcnt(pieces of THIS step) before the step's barrier,
-// so a piece issued in step s is visible from step s + 2.  (No filler pieces: a 1 KiB piece costs ~130 clocks of the CU's
-// intake whether or not it carries data -- with two zero-fill dummies per step the loaders were back at the MFMA time.)  Patches live in
+// patch is loaded, PT_APS = 2 patch pieces; it waits for them (vmcnt(0)) before the NEXT step's barrier -- the one barrier of
+// a step sits in the middle of the compute waves' step -- so a piece issued behind barrier M(s) is read from M(s + 1) on.
+// (No filler pieces to equalise the waves' piece counts: issuing a 1 KiB piece costs a loader ~130 clocks whether or not it
+// carries data.  The loaders have that time to spare today -- they wait 350 - 530 clocks per step -- and dropping the two
+// out-of-tile filter pieces a step still carries changed nothing: DESIGN.md section 4, experiment (iii).)  Patches live in
 // PT_NPB = 3 buffers: phase p is loaded (4 pieces per wave, over 2 steps) as soon as the last step that reads phase p - 3
 // is over; the host only selects this kernel when every phase is then complete two steps before its first read
 // (plan_fwd_patch).
