@@ -65,6 +65,7 @@ import torch.distributed as dist        # noqa: E402
 GFLOP_PER_IMAGE_ITERATION = 30.08
 GFLOP_PER_IMAGE = {'pix2pix': 93.1, 'vae': 1.64}       # per image of one train() call / step
 PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}           # MI355X_MICROARCH.md, dense
+SUSTAINED_TFLOPS = {'bf16': 1457.0}     # see roofline.power_bound_reference
 
 
 def cpu_baseline(args):
@@ -202,6 +203,11 @@ def roofline_of(timer, dtype, timer_steps, ms_per_step, with_traffic=True):
     traffic, traffic_src = pmc_traffic(kind) if with_traffic else (None, None)
     return {'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_TFLOPS[dtype], 'unit': 'TFLOP/s',
             'frac': achieved / PEAK_TFLOPS[dtype], 'traffic': traffic, 'traffic_source': traffic_src,
+            # informational: what a sustained MFMA loop reaches on this part under its power budget -- the library's 8192^3
+            # bf16 GEMM runs 0.93 MFMA-busy at 1.51 GHz effective = 1457 TF (profiles/r03_c_effective_clock.txt); `frac` above
+            # stays against the nominal dense peak of MI355X_MICROARCH.md
+            'power_bound_reference': {'tflops': SUSTAINED_TFLOPS.get(dtype), 'frac': (achieved / SUSTAINED_TFLOPS[dtype]) if dtype in SUSTAINED_TFLOPS else None,
+                                      'source': 'hipBLASLt 8192^3 bf16, SQ cycle counters: profiles/r03_c_effective_clock.txt'},
             'kernel': kind, 'launches': n, 'avg_launch_ms': tot_ms / n, 'flop_per_launch': fl / n,
             'measured': 'HIP events recorded by the library around every conv GEMM kernel launch (on the launch '
                         'stream) in %d instrumented eager steps run directly after the timed region (hipGraph '

@@ -2,7 +2,10 @@
 import sys
 import torch
 dev = torch.device('cuda:0')
-for (m, k, n) in [(98304, 5000, 400), (24576, 10000, 800), (98304, 5120, 416), (24576, 10240, 832), (8192, 8192, 8192)]:
+shapes = [(98304, 5000, 400), (24576, 10000, 800), (98304, 5120, 416), (24576, 10240, 832), (8192, 8192, 8192)]
+if len(sys.argv) == 4:                      # one shape: m k n
+    shapes = [tuple(int(v) for v in sys.argv[1:4])]
+for (m, k, n) in shapes:
     a = torch.randn(m, k, device=dev, dtype=torch.bfloat16)
     b = torch.randn(k, n, device=dev, dtype=torch.bfloat16)
     bt = torch.randn(n, k, device=dev, dtype=torch.bfloat16)
