@@ -132,7 +132,7 @@ struct JDec {
     while (l <= 16 && code > t.maxcode[l]) { code = (int)(bitbuf >> (32 - (l + 1))); ++l; }
     if (l > 16) return -1;
     bitbuf <<= l; bitcnt -= l;
-    return t.vals[t.valptr[l] + code - t.mincode[l]];
+    return t.vals[(t.valptr[l] + code - t.mincode[l]) & 255];      // (a corrupt table cannot index past the 256 values)
   }
   static int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
 };
@@ -227,6 +227,7 @@ int jpeg_headers(JDec& d) {
       if (s[0] != 8) return jpeg_fail("only 8-bit samples are supported");
       d.H = (s[1] << 8) | s[2]; d.W = (s[3] << 8) | s[4]; d.ncomp = s[5];
       if (d.W <= 0 || d.H <= 0) return jpeg_fail("empty image");
+      if ((long long)d.W * d.H > (1LL << 26)) return jpeg_fail("images above 64 M pixels are refused (corrupt header?)");
       if (d.ncomp != 1 && d.ncomp != 3) return jpeg_fail("only 1- and 3-component (grayscale, YCbCr / RGB) files are supported");
       if (se - s < 6 + 3 * d.ncomp) return jpeg_fail("short frame header");
       for (int i = 0; i < d.ncomp; ++i) {
