@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "tdg_igemm.h"
+#include "tdg_wgrad_patch.h"
 #include <type_traits>
 
 #define OOB_OFFSET 0xFFFFFF00u
@@ -4163,7 +4164,10 @@ static int wgrad_nsplit(const TdgConvDesc* d, int n_images, int* m_per_split) {
   if (want > max_split) want = max_split;
   if (want < 1) want = 1;
   if (want > 256) want = 256;
-  int per = (int)tdg_round_up(tdg_ceil_div(M, want), mr);
+  // 208-column LDS-DMA problems: splits of whole ring cycles (3 steps) of the patch-resident kernel, which runs its
+  // unrolled-by-stage loop to a multiple of 3 steps
+  const int unit = dma && wgrad_bn(d) == 208 ? 3 * mr : mr;
+  int per = (int)tdg_round_up(tdg_ceil_div(M, want), unit);
   *m_per_split = per;
   return tdg_ceil_div(M, per);
 }
@@ -4257,6 +4261,18 @@ static int bwd_filter_impl(const TdgConvDesc* d, int n_images, const void* x, in
     return mode == 1 ? launch_wgrad_dma<B, 1>(a, (hipStream_t)stream)
                      : (mode == 2 ? launch_wgrad_dma<B, 2>(a, (hipStream_t)stream) : launch_wgrad_dma<B, 0>(a, (hipStream_t)stream));
   };
+  // whole-image steps of a 208-column problem: the patch-resident kernel (tdg_wgrad_patch.hip) where its plan applies.
+  // TDG_WPATCH=0 (variant tests) keeps the slab kernel.
+  bool patched = false;
+  if (dma && bn == 208 && mode == 1 && !(getenv("TDG_WPATCH") && atoi(getenv("TDG_WPATCH")) == 0)) {
+    WpPlan wp;
+    if (tdg_wgrad_patch_plan(a, &wp)) {
+      rc = tdg_wgrad_patch_launch(a, wp, t_flops, (hipStream_t)stream);
+      if (rc) return rc;
+      patched = true;
+    }
+  }
+  if (!patched)
   rc = dma ? (bn == 208 ? go(std::integral_constant<int, 208>{}) : bn == 256 ? go(std::integral_constant<int, 256>{}) : go(std::integral_constant<int, 128>{}))
            : d->dtype == TDG_BF16 ? launch_wgrad<bf16_t>(a, veca, bn, (hipStream_t)stream)
                                   : launch_wgrad<float>(a, veca, bn, (hipStream_t)stream);

@@ -205,6 +205,50 @@ def test_conv_patch_resident_kernel(case, monkeypatch):
     assert 'igemm_fwd_patch_kernel' in pkg('_lib').load().tdg_last_kernel().decode()
 
 
+WGRAD_PATCH_CASES = [
+    (7, 16, 16, 200, 400, 5, 2),      # c2 geometry: one image per 64-row step, 25 slices, 20 K tiles of 32 (slice, tap) units
+    (25, 8, 8, 400, 800, 5, 2),       # c3: four images per step, ragged last step (25 images), four column tiles
+    (13, 8, 8, 200, 200, 5, 2),       # one column tile, ragged
+    (6, 16, 16, 40, 200, 5, 2),       # 5 slices: the last K tile is mostly padding units
+    (37, 4, 4, 400, 800, 5, 2),       # dc1 geometry: 2 x 2 outputs, 16 images per step; most taps fall outside the image
+    (5, 8, 8, 200, 400, 3, 1),        # stride 1, 9 taps: a K tile spans 5 slices (80-byte patch pixels)
+    (4, 16, 16, 104, 200, 5, 2),      # dc3: 13 slices (100 channels in a stride of 104)
+    (9, 16, 16, 48, 400, 4, 2),       # 4 x 4 filters (16 taps: a tile is exactly two slices)
+]
+
+
+@pytest.mark.parametrize('nw', ['8', '4'])
+@pytest.mark.parametrize('case', WGRAD_PATCH_CASES)
+def test_wgrad_patch_kernel(case, nw, monkeypatch):
+    """igemm_wgrad_patch_kernel (the gathered operand of the filter gradient resident in LDS as a patch of source pixels) in
+    both wave layouts against the float64 oracle and, bit for bit, against a second launch; the dispatch is asserted.
+    beta = 1 on a pre-filled gradient; the slab kernel (TDG_WPATCH=0) must agree to summation-order rounding."""
+    K = pkg('kernels')
+    monkeypatch.setenv('TDG_WPATCH_NW', nw)
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(11)
+    x = bf16_round(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    big, small, conv = make_conv(K, 1, n, h, w, cin, cout, k, s, dev)
+    dy = bf16_round(rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32))
+    big.set(x)
+    small.set(dy)
+    ref = T.conv2d_backprop_filter(x.astype(np.float64), (k, k, cin, cout), dy.astype(np.float64), s) + 0.5
+    outs = []
+    for rep in range(2):
+        dw = torch.full((k, k, cin, cout), 0.5, device=dev)
+        conv.bwd_filter(big.ptr(), small.ptr(), dw, n, beta=1.0)
+        assert 'igemm_wgrad_patch_kernel<bf16,256,208,%s' % nw in pkg('_lib').load().tdg_last_kernel().decode()
+        outs.append(dw.cpu().numpy())
+    assert relerr(outs[0], ref) < TOL[1]
+    assert np.array_equal(outs[0], outs[1])
+    monkeypatch.setenv('TDG_WPATCH', '0')
+    dw = torch.full((k, k, cin, cout), 0.5, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw, n, beta=1.0)
+    assert 'igemm_wgrad_dma_kernel' in pkg('_lib').load().tdg_last_kernel().decode()
+    assert relerr(dw.cpu().numpy(), outs[0]) < 1e-5
+
+
 @pytest.mark.parametrize('dtype', [0, 1])
 @pytest.mark.parametrize('case', [(2, 8, 8, 200, 400, 5, 2), (2, 16, 16, 128, 256, 4, 2), (3, 4, 4, 512, 512, 4, 2)])
 def test_conv_split_k_small_m(case, dtype, monkeypatch):
