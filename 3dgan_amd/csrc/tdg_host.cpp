@@ -67,12 +67,16 @@ struct JHuff {
   int mincode[18], maxcode[18], valptr[17];
   short look[512];                 // 9-bit lookahead: (length << 8) | value, 0 = longer than 9 bits
   bool present = false;
-  void build() {
+  // false: the code-length counts do not form a prefix code (more codes of some length than that length has left:
+  // libjpeg's "bogus Huffman table"); such a table would index past the 9-bit lookahead
+  bool build() {
     int code = 0, k = 0;
+    present = false;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = code;
       code += bits[l];
+      if (code > (1 << l)) return false;
       k += bits[l];
       maxcode[l] = bits[l] ? code - 1 : -1;
       code <<= 1;
@@ -88,6 +92,7 @@ struct JHuff {
       code <<= 1;
     }
     present = true;
+    return true;
   }
 };
 
@@ -96,6 +101,8 @@ struct JComp { int id, h, v, tq, td, ta, pred, bw, bh, dw, dh; unsigned char* pl
 struct JDec {
   const unsigned char* p; const unsigned char* end;
   unsigned bitbuf = 0; int bitcnt = 0; int marker = 0;
+  int padbits = 0;          // zero bits at the tail of bitbuf that stand for data the stream does not hold
+  bool overrun = false;     // ... and one of them has been consumed: the entropy-coded segment ended early
   unsigned short qt[4][64]; bool qt_ok[4] = {false, false, false, false};
   JHuff dc[4], ac[4];
   JComp comp[3]; int ncomp = 0, W = 0, H = 0, hmax = 1, vmax = 1, restart = 0;
@@ -113,25 +120,30 @@ struct JDec {
           else { marker = m; ++p; b = 0; }
         }
       }
+      else padbits += 8;
       bitbuf |= (unsigned)b << (24 - bitcnt);
       bitcnt += 8;
     }
+  }
+  void used(int n) {
+    bitbuf <<= n; bitcnt -= n;
+    if (bitcnt < padbits) { overrun = true; padbits = bitcnt < 0 ? 0 : bitcnt; }
   }
   int getbits(int n) {
     if (!n) return 0;
     if (bitcnt < n) fill();
     const int v = (int)(bitbuf >> (32 - n));
-    bitbuf <<= n; bitcnt -= n;
+    used(n);
     return v;
   }
   int decode(const JHuff& t) {
     if (bitcnt < 16) fill();
     const int lk = t.look[bitbuf >> 23];
-    if (lk) { const int l = lk >> 8; bitbuf <<= l; bitcnt -= l; return lk & 0xff; }
+    if (lk) { used(lk >> 8); return lk & 0xff; }
     int code = (int)(bitbuf >> 22), l = 10;
     while (l <= 16 && code > t.maxcode[l]) { code = (int)(bitbuf >> (32 - (l + 1))); ++l; }
     if (l > 16) return -1;
-    bitbuf <<= l; bitcnt -= l;
+    used(l);
     return t.vals[(t.valptr[l] + code - t.mincode[l]) & 255];      // (a corrupt table cannot index past the 256 values)
   }
   static int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
@@ -236,6 +248,9 @@ int jpeg_headers(JDec& d) {
         if (c.h < 1 || c.h > 2 || c.v < 1 || c.v > 2 || c.tq > 3) return jpeg_fail("sampling factors other than 1 and 2 are not supported");
         d.hmax = c.h > d.hmax ? c.h : d.hmax; d.vmax = c.v > d.vmax ? c.v : d.vmax;
       }
+      // a one-component scan is non-interleaved: one block per MCU in raster order whatever the frame header's
+      // sampling factors say (libjpeg decodes such files as if they were 1x1)
+      if (d.ncomp == 1) { d.comp[0].h = d.comp[0].v = 1; d.hmax = d.vmax = 1; }
       d.have_sof = true;
     } else if (m == 0xc2) {
       return jpeg_fail("progressive JPEG (SOF2) is not supported");
@@ -253,7 +268,7 @@ int jpeg_headers(JDec& d) {
         for (int l = 1; l <= 16; ++l) { t.bits[l] = s[l]; n += s[l]; }
         if (n > 256 || se - s < 17 + n) return jpeg_fail("short Huffman table");
         for (int i = 0; i < n; ++i) t.vals[i] = s[17 + i];
-        t.build();
+        if (!t.build()) return jpeg_fail("bogus Huffman table (its code lengths are not a prefix code)");
         s += 17 + n;
       }
     } else if (m == 0xdb) {
@@ -332,7 +347,7 @@ extern "C" int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigne
   for (int y = 0; y < my; ++y) {
     for (int x = 0; x < mx; ++x) {
       if (d.restart && todo == 0) {
-        d.bitbuf = 0; d.bitcnt = 0;                         // byte-align, then the RSTn marker (already seen, or still ahead)
+        d.bitbuf = 0; d.bitcnt = 0; d.padbits = 0;          // byte-align, then the RSTn marker (already seen, or still ahead)
         if (!d.marker) {
           while (d.p + 1 < d.end && !(d.p[0] == 0xff && d.p[1] >= 0xd0 && d.p[1] <= 0xd7)) ++d.p;
           if (d.p + 1 < d.end) { d.marker = d.p[1]; d.p += 2; }
@@ -348,8 +363,8 @@ extern "C" int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigne
             int blk[64] = {0};
             const int t = d.decode(d.dc[c.td]);
             if (t < 0 || t > 11) { cleanup(); return jpeg_fail("corrupt entropy-coded data (DC)"); }
-            c.pred += t ? JDec::extend(d.getbits(t), t) : 0;
-            blk[0] = c.pred * d.qt[c.tq][0];
+            c.pred = (int)((unsigned)c.pred + (unsigned)(t ? JDec::extend(d.getbits(t), t) : 0));     // (a corrupt stream may wrap; never UB)
+            blk[0] = (int)((long long)c.pred * d.qt[c.tq][0]);
             for (int k = 1; k < 64;) {
               const int rs = d.decode(d.ac[c.ta]);
               if (rs < 0) { cleanup(); return jpeg_fail("corrupt entropy-coded data (AC)"); }
@@ -361,6 +376,8 @@ extern "C" int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigne
               blk[z] = JDec::extend(d.getbits(s), s) * d.qt[c.tq][z];
               ++k;
             }
+            // tf.image.decode_image raises on a file cut inside its scan; so does this decoder (no grey tail)
+            if (d.overrun) { cleanup(); return jpeg_fail("the entropy-coded data ends (or meets a marker) before the last block"); }
             idct_islow(blk, c.plane + (size_t)((y * c.v + by) * 8) * c.bw + (x * c.h + bx) * 8, c.bw);
           }
       }

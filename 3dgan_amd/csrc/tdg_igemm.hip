@@ -3164,7 +3164,9 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   tdg_note_kernel(name);
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
   tdg_timing_start(name, t_flops, s);
-  const int abl = (BM == 192 && getenv("TDG_PATCH_ABL")) ? atoi(getenv("TDG_PATCH_ABL")) : 0;     // diagnostics (results are garbage)
+#ifdef TDG_STAMPS
+  // ablation instantiations (their results are garbage): compiled into the diagnostic library (build.sh stamps) only
+  const int abl = (BM == 192 && getenv("TDG_PATCH_ABL")) ? atoi(getenv("TDG_PATCH_ABL")) : 0;
   if constexpr (BM == 192) {
     if (abl == 1) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 1>), grid, block, lds, s, a);
     else if (abl == 2) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 2>), grid, block, lds, s, a);
@@ -3174,6 +3176,9 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   } else {
     hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
   }
+#else
+  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
+#endif
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_patch");
   return TDG_OK;
@@ -3182,7 +3187,11 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
 template <typename T>
 int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   constexpr int BM = 128;
-  static const int dbg = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+#ifdef TDG_STAMPS
+  static const int dbg = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;   // loop ablations (garbage results): diagnostic library only
+#else
+  const int dbg = 0;
+#endif
   const char* dma_env = getenv("TDG_DMA");          // diagnostics: 0 = never, 3 / 4 = force the 192 / 256-row tile
   const int dma_mode = dma_env ? atoi(dma_env) : 1;
   a.debug = dbg;
@@ -3885,7 +3894,10 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
     f.fd_pw = make_fastdiv(tp.PW);
     f.fd_ow = make_fastdiv(d->ow);
     f.fd_c = make_fastdiv(d->c);
-    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+    f.debug = 0;
+#ifdef TDG_STAMPS
+    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;     // (garbage results: diagnostic library only)
+#endif
     f.stamps = nullptr;
 #ifdef TDG_STAMPS
     f.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
@@ -4007,7 +4019,10 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
     f.KP = cp.KP; f.NT = cp.NT; f.pitch = cp.pitch; f.ke = cp.ke;
     f.TA = cp.TA; f.TW = cp.TW; f.ntr = cp.ntr; f.ntc = cp.ntc; f.HR = cp.HR; f.HC = cp.HC; f.dh_min = cp.dh_min; f.dw_min = cp.dw_min;
     f.p_off = cp.p_off;
-    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;
+    f.debug = 0;
+#ifdef TDG_STAMPS
+    f.debug = getenv("TDG_DEBUG_ABLATE") ? atoi(getenv("TDG_DEBUG_ABLATE")) : 0;     // (garbage results: diagnostic library only)
+#endif
     BwdClassPlan plan[IG_MAX_CLASSES];
     plan_bwd_classes(d, plan);
     for (int i = 0; i < 4; ++i) {

@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_wgrad_patch_ke
           const int ih = ih0[ks][h] + dh, iw = iw0[ks][h] + dw;
           const bool ok = uok && (unsigned)ih < (unsigned)SH && (unsigned)iw < (unsigned)SW;
           const int chunk = (prow0[ks][h] + ih) * pl.rp + iw * pl.nsl + ((int)sl - s0);
-          addrA[i][ks][h] = lds0 + (ok ? (unsigned)(WP_AOFF + WP_ZERO + (chunk << 4)) : 0u) + (unsigned)((p & 1) << 3);
+          // (a tap outside the image reads zeros from the stage's zero block, at the bank its pixel would have had: the
+          // layout search below then sees the same conflict pattern as for an interior tile)
+          const unsigned in_patch = (unsigned)(chunk << 4) + (unsigned)((p & 1) << 3);
+          addrA[i][ks][h] = lds0 + (ok ? (unsigned)(WP_AOFF + WP_ZERO) + in_patch : (unsigned)WP_AOFF + (in_patch & 0xf8u));
         }
     }
   }
@@ -382,7 +385,8 @@ static int wp_conflicts(const WgArgs& a, int nsl, int rp) {
                 const int dh = (signed char)(a.tap[tap] & 0xff), dw = (signed char)((a.tap[tap] >> 8) & 0xff);
                 const int ih = oh * a.sigma + dh, iw = ow * a.sigma + dw;
                 const bool ok = u < (a.C / 8) * a.ntaps && ih >= 0 && ih < a.SH && iw >= 0 && iw < a.SW;
-                addr[n++] = (ok ? (unsigned)(WP_AOFF + WP_ZERO + (((il * a.SH + ih) * rp + iw * nsl + sl) << 4)) : 0u) + (unsigned)((p & 1) << 3);
+                const unsigned in_patch = (unsigned)((((il * a.SH + ih) * rp + iw * nsl + sl) << 4)) + (unsigned)((p & 1) << 3);
+                addr[n++] = ok ? (unsigned)(WP_AOFF + WP_ZERO) + in_patch : (unsigned)WP_AOFF + (in_patch & 0xf8u);
               }
           int worst = 1;
           for (int b = 0; b < 32; ++b) {

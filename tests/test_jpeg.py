@@ -76,6 +76,70 @@ def test_unsupported_files_are_refused_by_name():
         jpeg.decode(ok[:len(ok) // 8])                              # cut inside the headers
 
 
+def _segment(data, marker):
+    """(offset of the segment's first payload byte, payload length) of the first `marker` segment."""
+    i = 2
+    while i + 4 <= len(data):
+        assert data[i] == 0xff
+        m, ln = data[i + 1], (data[i + 2] << 8) | data[i + 3]
+        if m == marker:
+            return i + 4, ln - 2
+        i += 2 + ln
+    raise AssertionError('no segment %02x' % marker)
+
+
+def test_corrupt_headers_are_refused_not_crashed_on():
+    """an over-subscribed Huffman table (bits[1] = 255 passes the count check) used to write far past the
+    9-bit lookahead table.  Mutated DHT / SOF / SOS bytes must come back as errors (or decode), never as a crash."""
+    data = bytearray(_encode(_picture(24, 24), quality=80))
+    off, _ = _segment(data, 0xc4)
+    n = sum(data[off + 1:off + 17])                           # values of the first table: keep the count, so the segment parses
+    assert 4 <= n <= 255
+    bad = bytearray(data)
+    bad[off + 1:off + 17] = bytes([n] + [0] * 15)             # n codes of length 1 (there are two)
+    with pytest.raises(_lib.TdgError, match='bogus Huffman table'):
+        jpeg.decode(bytes(bad))
+    bad = bytearray(data)
+    bad[off + 1:off + 17] = bytes([1, 3, n - 4] + [0] * 13)   # 1 code of length 1, then 3 of length 2 (only 2 are left)
+    with pytest.raises(_lib.TdgError, match='bogus Huffman table'):
+        jpeg.decode(bytes(bad))
+    # the advisor's file: a table of 255 one-bit codes with its 255 values present
+    big = bytes([0xff, 0xd8, 0xff, 0xc4]) + struct.pack('>H', 2 + 17 + 255) + bytes([0x00, 255] + [0] * 15) + bytes(range(255)) + bytes(data[2:])
+    with pytest.raises(_lib.TdgError, match='bogus Huffman table'):
+        jpeg.decode(big)
+    rng = np.random.default_rng(5)
+    for marker in (0xc4, 0xc0, 0xda, 0xdb):
+        off, ln = _segment(data, marker)
+        for _ in range(150):
+            bad = bytearray(data)
+            for _ in range(int(rng.integers(1, 4))):
+                bad[off + int(rng.integers(0, ln))] = int(rng.integers(0, 256))
+            try:
+                out = jpeg.decode(bytes(bad))
+                assert out.ndim == 3 and out.shape[2] == 3
+            except _lib.TdgError:
+                pass
+
+
+def test_grayscale_with_sampling_factors_in_the_frame_header():
+    """ADVICE r3 (medium): a one-component file whose SOF says 2x2 is still one block per MCU (non-interleaved scan);
+    libjpeg (Pillow) decodes it exactly like the 1x1 file."""
+    data = bytearray(_encode(_picture(40, 52)[..., 0], quality=80))
+    off, _ = _segment(data, 0xc0)
+    assert data[off + 5] == 1 and data[off + 7] == 0x11
+    data[off + 7] = 0x22
+    assert np.array_equal(jpeg.decode(bytes(data)), _pil(bytes(data)))
+
+
+def test_truncated_scan_is_an_error():
+    """tf.image.decode_image raises on a file cut inside its entropy-coded data; no grey tail with a success status."""
+    data = _encode(_picture(64, 64), quality=90)
+    with pytest.raises(_lib.TdgError, match='before the last block'):
+        jpeg.decode(data[:int(len(data) * 0.6)])
+    assert np.array_equal(jpeg.decode(data), _pil(data))          # the whole file still decodes
+    assert np.array_equal(jpeg.decode(data[:-2]), _pil(data))     # ... also without its EOI marker (every block is there)
+
+
 def test_floorplan_plugin_reads_jpeg_records(tmp_path):
     """A floorplans.train.tfrecords file framed here byte by byte (tf.train.Example: `image` = the JPEG file's bytes) ->
     the plugin's 64 x 64 uint8 images == the same pipeline on Pillow's decode."""
