@@ -78,6 +78,9 @@ __device__ __forceinline__ bf16x8 wp_frag(unsigned lo_addr, unsigned hi_addr) {
   const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4_t)((lds_c_t) nullptr + hi_addr));
   return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
+__device__ __forceinline__ void wp_mfma_agpr(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
 }  // namespace
 
 template <int NW, int NSLOT>
@@ -248,8 +251,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_wgrad_patch_ke
     bf16x8 FA[2][RT], FG[2][TNW];
     auto mma_tile = [&](auto ks_c, auto t_c) {
       constexpr int ks = decltype(ks_c)::value, t = decltype(t_c)::value;
+      if constexpr (NW == 4) {
+        // one wave per SIMD, 512 registers: the 56 accumulators are pinned to AGPRs by the asm constraint (given the builtin,
+        // hipcc renames them between the unrolled stage bodies and fills the loop with v_accvgpr moves: 432 per 288 MFMAs)
 #pragma unroll
-      for (int i = 0; i < RT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FG[ks][t], FA[ks][i], acc[i][t], 0, 0, 0);
+        for (int i = 0; i < RT; ++i)
+          wp_mfma_agpr(acc[i][t], FG[ks][t], FA[ks][i]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < RT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FG[ks][t], FA[ks][i], acc[i][t], 0, 0, 0);
+      }
     };
     auto readA = [&](auto st_c, auto ks_c, auto i_c) {
       constexpr int st = decltype(st_c)::value, ks = decltype(ks_c)::value, i = decltype(i_c)::value;
@@ -330,6 +341,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_wgrad_patch_ke
       body(IntC<2>{});
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the trailing (out-of-range, zero-fill) pieces
+    if constexpr (NW == 4) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the asm MFMAs' results (no compiler-known hazard) before the epilogue reads them
   };
   if (wn == 0) run(IntC<TN>{});
   else run(IntC<TN1>{});

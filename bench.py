@@ -130,6 +130,37 @@ def cpu_baseline_pix2pix(batch=8):
                       'f32 torch-autograd port of the oracle, %d threads (CPU restatement, not TensorFlow)' % (batch, dt, cores)}
 
 
+def cpu_baseline_vae(batch=512, iters=6):
+    """Config 5's CPU figure (its per-GPU share, batch 512): the oracle's torch-autograd statement of models/vae.py:25-151
+    (oracle/vae_ref.py: torch_losses; only decoder_loss is differentiated, as the reference's compute_gradients does) with an
+    Adam step per call, f32, on the host cores."""
+    from oracle import vae_ref as VR
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))
+    torch.set_num_threads(cores)
+    P = {k: torch.tensor(v, requires_grad=True) for k, v in VR.init_params(200, 0, np.float32).items()}
+    opt = torch.optim.Adam(list(P.values()), lr=1e-4, betas=(0.5, 0.9), eps=1e-8)
+    g = torch.Generator().manual_seed(1234)
+
+    def step():
+        x, eps = torch.rand(batch, 64, 64, 3, generator=g), torch.randn(batch, 200, generator=g)
+        opt.zero_grad(set_to_none=True)
+        d_loss, _ = VR.torch_losses(P, x, eps)
+        d_loss.backward()
+        opt.step()
+    step()                                          # untimed warm-up (allocator, thread pool)
+    t0 = time.time()
+    for _ in range(iters):
+        step()
+    dt = time.time() - t0
+    return {'value': iters * batch / dt, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%d optimizer steps at batch %d in %.1f s after one warm-up step, f32 torch-autograd port of the oracle, '
+                      '%d threads (CPU restatement, not TensorFlow)' % (iters, batch, dt, cores)}
+
+
 def newest_pmc_file():
     """The committed PMC summary (profiles/rNN_*_pmc_fetch_write_per_kernel.json) of the newest build."""
     d = os.path.join(ROOT, 'profiles')
@@ -405,6 +436,8 @@ def main():
                     sec['%s_bs%d' % (m, 64 if m == 'pix2pix' else 512)] = secondary_leg(m, K.BF16, K, rt, data, models)
             if 'pix2pix' in legs and not args.no_cpu_baseline:
                 sec['pix2pix_bs64']['cpu_baseline'] = cpu_baseline_pix2pix()
+            if 'vae' in legs and not args.no_cpu_baseline:
+                sec['vae_bs512']['cpu_baseline'] = cpu_baseline_vae()
             if args.dtype == 'bf16' and args.model == 'iwgan' and 'f32' in legs:
                 # the parity dtype on the headline workload: exact-f32 MFMA path
                 s32, r32 = headline_replica('f32')

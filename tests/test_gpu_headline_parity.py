@@ -121,6 +121,11 @@ def test_headline_conv_launches_bf16(case):
     ref = T.lrelu(T.conv2d(x[idx].astype(np.float64), W64, s) + b)
     assert relerr(got[idx], ref) < BF16_TOL, kern
     assert np.isfinite(got).all()
+    # a second launch of the same problem is bit-equal (a race between the loader and compute waves of the one-barrier-per-step
+    # schedule would show here: 1024 workgroups, four rounds per launch)
+    small.set(np.zeros_like(got))
+    conv.fwd(big.ptr(), small.ptr(), n, K.epilogue(bias=torch.tensor(b, device=dev), act=K.ACT_LRELU, leak=0.2))
+    assert np.array_equal(small.get(), got)
     # every image, cheaply: column sums of the output against the oracle's linearity (sum over images of the
     # PRE-activation is the conv of the image sum) is not available behind the lrelu, so check a second random subset
     idx2 = rng.integers(0, n, 16)
@@ -136,6 +141,9 @@ def test_headline_conv_launches_bf16(case):
     ref = T.conv2d_backprop_input((len(idx), h, w, cin), W64, dy[idx].astype(np.float64), s) * \
         T.lrelu_grad_mask(x[idx].astype(np.float64))
     assert relerr(got[idx], ref) < BF16_TOL, kern
+    out2 = big.like()
+    conv.bwd_data(small.ptr(), out2.ptr(), n, K.epilogue(mask_mode=K.MASK_LRELU, mask_src=mask.ptr(), leak=0.2))
+    assert np.array_equal(out2.get(), got)                       # two launches, bit-equal
     # ---- filter gradient over all 1536 images (default split count), oracle accumulated over image chunks
     dw = torch.zeros(k, k, cin, cout, device=dev)
     conv.bwd_filter(big.ptr(), small.ptr(), dw, n)
@@ -143,6 +151,10 @@ def test_headline_conv_launches_bf16(case):
     for i0 in range(0, n, 128):
         ref += T.conv2d_backprop_filter(x[i0:i0 + 128].astype(np.float64), Wt.shape, dy[i0:i0 + 128].astype(np.float64), s)
     assert relerr(dw.cpu().numpy(), ref) < BF16_TOL
+    assert 'igemm_wgrad_patch_kernel<bf16,256,208,8' in last_kernel(), last_kernel()     # the default dispatch of round 4
+    dw_b = torch.zeros(k, k, cin, cout, device=dev)
+    conv.bwd_filter(big.ptr(), small.ptr(), dw_b, n)
+    assert torch.equal(dw, dw_b)                                 # two launches, bit-equal (fixed slab order, no atomics)
     # ---- two-source filter gradient as the D step issues it: rows of [h(x) | h(g)] (1024 images) from one tensor,
     # the 512 tangent rows from another, against ONE delta tensor (engine.SeqNet.merged_wgrad)
     n_first = 1024
@@ -447,3 +459,29 @@ def test_pix2pix_bench_size_bf16_vs_f32():
     keys = [k for k in gt if not k.endswith('decoder/BatchNorm_7/beta')]          # (a scalar has no direction)
     assert_direction_and_scale(g16, g32, keys, 'pix2pix bs64 bf16 vs f32 (G)')
     assert_direction_and_scale(d16, d32, list(dt), 'pix2pix bs64 bf16 vs f32 (D)')
+
+
+def test_graph_replay_equals_eager_at_the_timed_size():
+    """The path bench.py times -- hipGraph replay of the D / G step bodies, bf16, B = 512, L = 200 -- against the same steps
+    launched eagerly: variables, optimizer step counts and reported losses bit for bit after three train_func calls (eager
+    warm-up, capture, replay in the graph run).  (replay == eager was asserted at small sizes only.)"""
+    gan, rt, data, K = pkg('models.gan'), pkg('runtime'), pkg('data'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    results = []
+    for use_graphs in (False, True):
+        args = headline_args()
+        args.use_graphs = use_graphs
+        sess = rt.Session(device=dev, dtype=K.BF16, seed=3, rank=0, world_size=1)
+        rep = gan.GanReplica(data.SyntheticSource(4 * B, SHAPE, B, dev, seed=5), args, sess)
+        for _ in range(3):
+            out = rep.train_func()
+        torch.cuda.synchronize()
+        assert bool(rep._graphs) == use_graphs
+        results.append((rep.variables(), out, rep.d_opt.t, rep.g_opt.t))
+        del rep, sess
+        torch.cuda.empty_cache()
+    (va, oa, ta, tga), (vb, ob, tb, tgb) = results
+    assert (ta, tga) == (tb, tgb) == (15, 3)
+    assert oa == ob, (oa, ob)
+    for k in va:
+        assert np.array_equal(va[k], vb[k]), k

@@ -1,0 +1,47 @@
+"""Diagnostics: one kernel in a loop for a stated time (for power / clock / throttle sampling beside it: tools/power_probe.sh).
+usage: python tools/loop_kernel.py fwd|bwd_data|wgrad|matmul SECONDS  ->  prints launches, ms per launch, TFLOP/s"""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+K = importlib.import_module('3dgan_amd.kernels')
+
+
+def main(what, seconds):
+    dev = torch.device('cuda:0')
+    if what == 'matmul':
+        a = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
+        fn, fl = (lambda: torch.matmul(a, b)), 2.0 * 8192 ** 3
+    else:
+        n, h, w, cin, cout, k, s = 1536, 8, 8, 400, 800, 5, 2          # the critic's c3 on [x | g | x_hat]
+        big, small = K.Act(n, h, w, cin, K.BF16, dev), K.Act(n, 4, 4, cout, K.BF16, dev)
+        big.buf.copy_(torch.randn_like(big.buf.float()).to(big.buf.dtype))
+        small.buf.copy_(torch.randn_like(small.buf.float()).to(small.buf.dtype))
+        conv = K.Conv(big, small, k, k, s, 1, 1)
+        conv.pack(torch.randn(k, k, cin, cout, device=dev) * 0.05)
+        dw = torch.zeros(k, k, cin, cout, device=dev)
+        out = big.like()
+        fn = {'fwd': lambda: conv.fwd(big.ptr(), small.ptr(), n), 'bwd_data': lambda: conv.bwd_data(small.ptr(), out.ptr(), n),
+              'wgrad': lambda: conv.bwd_filter(big.ptr(), small.ptr(), dw, n)}[what]
+        fl = conv.flops(n)
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    t0, n_l = time.time(), 0
+    while time.time() - t0 < seconds:
+        for _ in range(200):
+            fn()
+        torch.cuda.synchronize()
+        n_l += 200
+    dt = time.time() - t0
+    print('%s: %d launches in %.1f s, %.4f ms per launch, %.0f TFLOP/s' % (what, n_l, dt, dt / n_l * 1e3, fl * n_l / dt / 1e12), flush=True)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], float(sys.argv[2]))
