@@ -97,6 +97,18 @@ def init_params(cfg, seed=0, dtype=np.float32):
     return P
 
 
+# Test hook ("kink-resolved" comparisons, tests/test_gpu_distributed.py, tests/test_oracle_towers.py): an object with
+#   mask(tag, layer, pre, default, lo) -> derivative mask
+# may flip the (l)relu derivative (between 1 and `lo`) of entries whose pre-activation lies within floating-point rounding
+# of the kink.  `tag` names the pass ('real' / 'fake' / 'hat' of the critic, 'g' of the generator); the first-order backward
+# and the penalty's tangent pass ask with the same (tag, layer), so a flip is applied consistently.  None: plain masks.
+KINK = None
+
+
+def _act_mask(tag, layer, pre, default, lo):
+    return default if KINK is None else KINK.mask(tag, layer, pre, default, lo)
+
+
 def split_params(P):
     g = {k: v for k, v in P.items() if k.startswith('generator/')}
     d = {k: v for k, v in P.items() if k.startswith('discriminator/')}
@@ -142,7 +154,7 @@ def g_backward(P, cache, dg_flat, cfg):
     for i in range(4, 0, -1):
         name, bn = specs[i - 1]
         if bn:
-            dpre = dh * T.relu_grad_mask(cache['pre%d' % i])
+            dpre = dh * _act_mask('g', i, cache['pre%d' % i], T.relu_grad_mask(cache['pre%d' % i]), 0.0)
             dy, grads[g_bn_name(i)] = T.batch_norm_train_backward(dpre, cache['bn%d' % i])
         else:
             dy = dh * (1.0 - cache['post%d' % i] ** 2)
@@ -151,7 +163,7 @@ def g_backward(P, cache, dg_flat, cfg):
         grads[g + name + '/weights'] = T.conv2d_transpose_backprop_filter(cache['in%d' % i], K.shape, dy, 2)
         dh = T.conv2d_transpose_backprop_input(K, dy, 2)
     dh = dh.reshape(n, -1)
-    dpre = dh * T.relu_grad_mask(cache['pre0'])
+    dpre = dh * _act_mask('g', 0, cache['pre0'], T.relu_grad_mask(cache['pre0']), 0.0)
     dy, grads[g_bn_name(0)] = T.batch_norm_train_backward(dpre, cache['bn0'])
     grads[g + 'fc1/bias'] = dy.sum(axis=0)
     grads[g + 'fc1/weights'] = cache['z'].T @ dy
@@ -159,11 +171,11 @@ def g_backward(P, cache, dg_flat, cfg):
 
 
 # --------------------------------------------------------------------------- discriminator
-def d_forward(P, x_flat, cfg, bn_pass=0):
+def d_forward(P, x_flat, cfg, bn_pass=0, tag=None):
     """models/gan.py:257-287.  Returns (d [rows], cache).  `bn_pass` selects the beta set."""
     L = cfg.L
     d = 'discriminator/vars/'
-    cache = {}
+    cache = {'tag': tag or ('real', 'fake')[bn_pass]}
     h = x_flat.reshape(-1, cfg.H, cfg.W, cfg.C)
     for i, name in enumerate(['c1', 'c2', 'c3']):
         cache['in%d' % i] = h
@@ -200,7 +212,7 @@ def d_backward(P, cache, dd, cfg, bn_pass=0, want_params=True, want_dx=True):
     dx = None
     for i in (2, 1, 0):
         name = ['c1', 'c2', 'c3'][i]
-        dy = dh * T.lrelu_grad_mask(cache['pre%d' % i])
+        dy = dh * _act_mask(cache['tag'], i, cache['pre%d' % i], T.lrelu_grad_mask(cache['pre%d' % i]), 0.2)
         if cfg.d_bn and i > 0:
             dy, dbeta = T.batch_norm_train_backward(dy, cache['bn%d' % i])
             if want_params:
@@ -236,7 +248,7 @@ def gradient_penalty(P, x, g, alpha, cfg, want_param_grads=True):
     assert not cfg.d_bn, 'gradient penalty is only defined for the BN-free iwgan critic'
     d = 'discriminator/vars/'
     xhat = x + alpha * (g - x)                                        # :225-226
-    dhat, cache = d_forward(P, xhat, cfg)
+    dhat, cache = d_forward(P, xhat, cfg, tag='hat')
     ones = np.ones_like(dhat)                                         # tf.gradients sums the outputs
     v, _, deltas = d_backward(P, cache, ones, cfg, want_params=False, want_dx=True)
     if getattr(cfg, 'gp_per_sample', False):                          # opt-in: one norm per image
@@ -255,7 +267,7 @@ def gradient_penalty(P, x, g, alpha, cfg, want_param_grads=True):
         K = P[d + name + '/weights']
         grads[d + name + '/weights'] = T.conv2d_backprop_filter(t, K.shape, deltas[i], 2)
         grads[d + name + '/bias'] = np.zeros_like(P[d + name + '/bias'])
-        t = T.conv2d(t, K, 2) * T.lrelu_grad_mask(cache['pre%d' % i])
+        t = T.conv2d(t, K, 2) * _act_mask('hat', i, cache['pre%d' % i], T.lrelu_grad_mask(cache['pre%d' % i]), 0.2)
     tf_ = t.reshape(-1, cfg.fc2_in)
     grads[d + 'fc2/weights'] = tf_.sum(axis=0).reshape(-1, 1)
     grads[d + 'fc2/bias'] = np.zeros_like(P[d + 'fc2/bias'])

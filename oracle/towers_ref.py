@@ -46,21 +46,38 @@ class GanTowers:
     def rescale(x01):
         return 2.0 * (x01.reshape(x01.shape[0], -1) - 0.5)                           # models/gan.py:49-50
 
-    def d_step(self, xs, zs, alphas, follow=None):
-        tower = [G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg)[1] for x, z, a in zip(xs, zs, alphas)]
-        self.last_d_grads = T.average_gradients(tower)                               # models/gan.py:77
+    def d_grads(self, xs, zs, alphas):
+        """The tower mean of the critic's gradients at the current variables (no update)."""
+        tower = []
+        for r, (x, z, a) in enumerate(zip(xs, zs, alphas)):
+            if G.KINK is not None:
+                G.KINK.tower = r
+            tower.append(G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg)[1])
+        return T.average_gradients(tower)                                            # models/gan.py:77
+
+    def d_step(self, xs, zs, alphas, follow=None, grads=None):
+        self.last_d_grads = grads if grads is not None else self.d_grads(xs, zs, alphas)
         self.d_opt.apply(self.P, follow if follow is not None else self.last_d_grads)    # :81
 
-    def g_step(self, xs, zs, alphas, follow=None):
+    def g_grads(self, xs, zs, alphas, want_report=True):
+        tower, rep = [], None
+        for r, (x, z, a) in enumerate(zip(xs, zs, alphas)):
+            if G.KINK is not None:
+                G.KINK.tower = r
+            gl, gg, _ = G.g_loss_and_grads(self.P, z, self.cfg)
+            tower.append(gg)
+            if want_report:
+                dl, _, _ = G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg, want_grads=False)
+                rep = {'g_loss': float(gl), 'd_loss': float(dl)}
+        return T.average_gradients(tower), rep                                       # :76
+
+    def g_step(self, xs, zs, alphas, follow=None, grads=None):
         """[g_train_op, losses] (models/gan.py:172): the losses are those of the LAST tower's batch, on the
         variables before this step's update."""
-        tower, rep = [], None
-        for x, z, a in zip(xs, zs, alphas):
-            gl, gg, _ = G.g_loss_and_grads(self.P, z, self.cfg)
-            dl, _, _ = G.d_loss_and_grads(self.P, self.rescale(x), z, a, self.cfg, want_grads=False)
-            tower.append(gg)
-            rep = {'g_loss': float(gl), 'd_loss': float(dl)}
-        self.last_g_grads = T.average_gradients(tower)                               # :76
+        if grads is None:
+            self.last_g_grads, rep = self.g_grads(xs, zs, alphas)
+        else:
+            self.last_g_grads, rep = grads
         self.g_opt.apply(self.P, follow if follow is not None else self.last_g_grads)    # :80
         return rep
 

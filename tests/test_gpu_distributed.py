@@ -131,14 +131,33 @@ def _oracle_towers(model, init, hip_grads=None, world=2):
             losses.append(tw.report(as_pairs(take(['x', 'y']))))
         return num(tw.P), steps, losses
     from oracle import gan_ref as G
+    import _kinks
     s = TI.SIZES[model]
     cfg = G.make_cfg(model, s['shape'], s['L'], s['B'])
     tw = TW.GanTowers(P, cfg, args)
+
+    def kink_resolved(compute, hip):
+        """The oracle's mean gradients at the current variables -- with, where the plain evaluation misses 1e-3 of the HIP
+        run's, the derivative of at most two pre-activations within 1e-5 of zero taken on the other side (tests/_kinks.py)."""
+        if hip is None:
+            return compute(), None
+        worst = lambda g: max(_rel(hip[k], v) for k, v in g.items() if not _zero_gradient_variable(model, k))
+        g, flips, w, near = _kinks.resolve(compute, worst, bound=1e-3, tol=1e-5)
+        resolved.append((len(steps), w, flips, near))
+        return g, flips
+    resolved = KINK_LOG[model] = []
     for _ in range(TI.iterations(model)):
         for _d in range(TI.N_DISC):
-            tw.d_step(*take(['x', 'z', 'alpha']), follow=follow())
+            xs = take(['x', 'z', 'alpha'])
+            hip = follow()
+            g, _ = kink_resolved(lambda: tw.d_grads(*xs), hip)
+            tw.d_step(None, None, None, follow=hip, grads=g)
             steps.append(tw.last_d_grads)
-        losses.append(tw.g_step(*take(['x', 'z', 'alpha']), follow=follow()))
+        xs = take(['x', 'z', 'alpha'])
+        hip = follow()
+        rep = tw.g_grads(*xs)[1]                                       # the reported losses (plain masks: forward values only)
+        g, _ = kink_resolved(lambda: tw.g_grads(*xs, want_report=False)[0], hip)
+        losses.append(tw.g_step(None, None, None, follow=hip, grads=(g, rep)))
         steps.append(tw.last_g_grads)
     return tw.P, steps, losses
 
@@ -179,6 +198,7 @@ def _cos(a, b):
 # direction only.  A dropped exchange is an O(1) error on the FIRST step already (tower gradients on different shards differ
 # by far more than 2e-2 of their max) and is caught bit-exactly by the shards-vs-towers rehearsal above.
 # (first-step bound, (later-step max bound, later-step cosine bound, bound that at most KINK_FRAC of a tensor's entries may exceed))
+KINK_LOG = {}       # model -> [(optimizer step, deviation after resolution, flipped entries or None, near-zero pre-activations)]
 BOUNDS = {'iwgan': (1e-3, (2e-2, 0.9999, 1e-3)), 'wgan': (1e-3, (2e-2, 0.9999, 1e-3)),
           'vae': (1e-3, (0.15, 0.9999, None)), 'pix2pix': (2e-2, (None, 0.98, None))}
 KINK_FRAC = 0.02
@@ -199,9 +219,10 @@ def test_two_replicas_match_the_oracle_tower_mean_f32(tmp_path, model, port):
     P, steps, losses = _oracle_towers(model, init, hip_grads)
     n_steps = len([k for k in out.files if k.startswith('nstep.')])
     assert n_steps == len(steps)
-    table = []
+    table, norm_ratio = [], []
     for i, ref in enumerate(steps):
         worst_rel, worst_cos, worst_frac = (0.0, ''), (1.0, ''), (0.0, '')
+        lo_hi = [1.0, 1.0]
         for n, g in ref.items():
             if _zero_gradient_variable(model, n):
                 continue
@@ -209,9 +230,30 @@ def test_two_replicas_match_the_oracle_tower_mean_f32(tmp_path, model, port):
             r, c = _rel(got, g), _cos(got, g)
             worst_rel, worst_cos = max(worst_rel, (r, n)), min(worst_cos, (c, n))
             worst_frac = max(worst_frac, (_frac_beyond(got, g, 1e-3), n))
+            ng = np.linalg.norm(np.asarray(g, np.float64).ravel())
+            if ng > 0:
+                q = float(np.linalg.norm(np.asarray(got, np.float64).ravel()) / ng)
+                lo_hi = [min(lo_hi[0], q), max(lo_hi[1], q)]
         table.append((i, worst_rel, worst_cos, worst_frac))
+        norm_ratio.append(lo_hi)
+    # a scale error (a wrong 1/n, a dropped or doubled contribution) cannot hide behind a direction-only bound: every
+    # tensor's norm within 1 % of the oracle's at every step, 3 % for pix2pix's later steps
+    print('%s per-tensor norm ratio HIP / oracle per step: %s' % (model, ['%.4f..%.4f' % tuple(q) for q in norm_ratio]))
+    for i, (qlo, qhi) in enumerate(norm_ratio):
+        slack = 0.03 if model == 'pix2pix' and i >= 2 else 0.01
+        assert 1.0 - slack <= qlo and qhi <= 1.0 + slack, (i, qlo, qhi)
     print('\n'.join('%s step %d: worst rel %.2e (%s), worst cos %.6f (%s), largest share of entries beyond 1e-3 of the max %.2e (%s)' %
                     (model, i, r[0], r[1], c[0], c[1], f[0], f[1]) for i, r, c, f in table))
+    # iwgan / wgan: the north-star's 1e-3 on EVERY entry of EVERY optimizer step, kinks resolved: a step either agrees as
+    # it stands or agrees once at most two pre-activations within 1e-5 of zero take the other side of their (l)relu kink
+    # (the kink explanation asserted, not assumed).  The free-form bounds below stay as a second check.
+    if model in ('iwgan', 'wgan'):
+        for i, w, flips, near in KINK_LOG[model]:
+            print('%s step %d: max deviation %.2e of the tensor maximum with %s (%d pre-activations within 1e-5 of zero)' % (
+                model, i, w, 'plain masks' if flips == () else 'flipped %s' % (flips,), near))
+        assert len(KINK_LOG[model]) == n_steps
+        for i, w, flips, near in KINK_LOG[model]:
+            assert flips is not None and w < 1e-3, (i, w, flips, near)
     first, (later_rel, later_cos, later_bulk) = BOUNDS[model]
     per_iter = TI.steps_per_iteration(model) - (1 if model == 'pix2pix' else 0)        # (pix2pix's third pass is the report)
     identical_state = {0} if model in ('vae',) else {0, per_iter - 1}                    # first critic step, first generator step
