@@ -200,7 +200,10 @@ def _cos(a, b):
 # (first-step bound, (later-step max bound, later-step cosine bound, bound that at most KINK_FRAC of a tensor's entries may exceed))
 KINK_LOG = {}       # model -> [(optimizer step, deviation after resolution, flipped entries or None, near-zero pre-activations)]
 BOUNDS = {'iwgan': (1e-3, (2e-2, 0.9999, 1e-3)), 'wgan': (1e-3, (2e-2, 0.9999, 1e-3)),
-          'vae': (1e-3, (0.15, 0.9999, None)), 'pix2pix': (2e-2, (None, 0.98, None))}
+          'vae': (1e-3, (2e-2, 0.9999, None)), 'pix2pix': (1e-2, (6e-2, 0.9999, None))}
+# (round 4, oracle following the HIP run: vae later steps 2.5e-3 / 8.3e-3 with cosine >= 0.999997; pix2pix first steps 2.5e-3 (D) /
+#  6.4e-3 (G), later 1.6e-6 / 3.6e-2 with cosine 0.999996 -- gpurun_out/r4k_dist.log; the bounds above are those values with
+#  margin, in VALUE and direction, plus the per-tensor norm ratio within 1 % (3 % pix2pix later steps) asserted below)
 KINK_FRAC = 0.02
 
 
