@@ -28,6 +28,10 @@ struct IgClass {
   // (a + dhq, b + dwq) of a [QH, QW] lattice per image, dhq = (dh - ph) / sigma
   int ngroups, QH, QW;
   FastDiv fd_qhw, fd_qw;   // divide by QH * QW, by QW
+  // block tiles of igemm_fwd_patch_kernel (nbh * nbw > 1; 0 / 1: whole images): GH, GW, fd_ghw, fd_gw then describe ONE BLOCK of
+  // an image's anchor grid, rows m run block by block (nbh x nbw blocks per image), and [QH, QW] is the block's lattice
+  // window incl. `halo` pixels on every side
+  int nbh, nbw, halo;
   struct { int t0, nt, ph, pw; } grp[4];   // (ints: the kernel reads them with scalar dword loads)
 };
 

@@ -37,6 +37,14 @@
 #define TDG_STAMP(var) do { } while (0)
 #endif
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <typename T>
 struct Mma;
 template <>
@@ -1037,10 +1045,16 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
     const int m = m0 + tid;
     long long p = -1;
     if (m < M) {
-      const unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
+      unsigned nb = fd_div((unsigned)m, cl.fd_ghw);
       const unsigned rem = (unsigned)m - nb * (unsigned)(cl.GH * cl.GW);
-      const unsigned a = fd_div(rem, cl.fd_gw);
-      const unsigned b = rem - a * (unsigned)cl.GW;
+      unsigned a = fd_div(rem, cl.fd_gw);
+      unsigned b = rem - a * (unsigned)cl.GW;
+      if (cl.nbh * cl.nbw > 1) {                       // block tiles (igemm_fwd_patch_kernel): nb counts blocks, (a, b) are block-local
+        const unsigned nblk = (unsigned)(cl.nbh * cl.nbw), img = nb / nblk, br = nb - img * nblk, bi = br / (unsigned)cl.nbw;
+        a += bi * (unsigned)cl.GH;
+        b += (br - bi * (unsigned)cl.nbw) * (unsigned)cl.GW;
+        nb = img;
+      }
       p = (long long)(((size_t)(nb * (unsigned)args.OH + a * (unsigned)args.os + (unsigned)cl.oh0) * (unsigned)args.OW +
                        b * (unsigned)args.os + (unsigned)cl.ow0) * (size_t)Cso);
     }
@@ -1114,7 +1128,7 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
     constexpr int G = NTHR / BN > 0 ? NTHR / BN : 1;
     float* sRed = reinterpret_cast<float*>(smem + BM * PE + BM * 8);
     __syncthreads();
-    const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW) : M;
+    const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW * (cl.nbh * cl.nbw > 1 ? cl.nbh * cl.nbw : 1)) : M;
     const int rows_valid = max(0, min(BM, mlim - m0));
     const int col = tid % BN, grp = tid / BN;
     const bool bnm = args.col_mode == TDG_COL_BN;
@@ -1182,10 +1196,14 @@ __device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[
     if constexpr (ABL == 1) fb[t2] = fb[t2 & 1];
     else if constexpr (t2 < NT) fb[t2] = *reinterpret_cast<const bf16x8*>(pB + (t2 - TN) * 16 * IG_BKB + coff1);
     else fb[t2] = *reinterpret_cast<const bf16x8*>(pBn + (t2 - NT) * 16 * IG_BKB + coff0);       // the next step's first tiles
-    if constexpr (j >= 1 && j <= TM && ABL != 2) fa0[j - 1] = pt_lds_frag(a0n[j - 1]);   // (tile TN no longer reads fa0)
+    // the next step's A fragments into fa0 (tile TN no longer reads it): one per tile from the second tile on where the half has
+    // more tiles than the wave has row tiles (208 / 128 columns), else spread over all of the half's tiles (64 columns: TN = TM)
+    constexpr int a_lo = TN > TM ? (j >= 1 && j <= TM ? j - 1 : 0) : (j * TM) / TN;
+    constexpr int a_hi = TN > TM ? (j >= 1 && j <= TM ? j : 0) : ((j + 1) * TM) / TN;
+    if constexpr (ABL != 2) static_for<a_lo, a_hi>([&](auto i_c) { constexpr int i = decltype(i_c)::value; fa0[i] = pt_lds_frag(a0n[i]); });
 #pragma unroll
     for (int i = 0; i < TM; ++i) Mma<bf16_t>::run(acc[i][j], fb[t], fa1[i]);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1 + ((j >= 1 && j <= TM) ? 1 : 0), 0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1 + (a_hi - a_lo), 0);
     __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
     patch_half1<TM, TN, ABL, t + 1>(acc, fa0, fa1, fb, smem, a0n, pB, pBn, coff0, coff1);
   }
@@ -1193,20 +1211,25 @@ __device__ __forceinline__ void patch_half1(f32x4 (&acc)[TM][TN], bf16x8 (&fa0)[
 
 // ABL (diagnostic instantiations, TDG_PATCH_ABL): 1 = no B fragment reads in the loop, 2 = no A fragment reads, 3 = no address arithmetic,
 // 4 = no LDS-DMA pieces in the loop
-template <int BM, int BN, int ABL>
+// CK: 16-byte chunks (8 channels) per K slice: 5 (the GAN's 200 / 400 / 800 channels) or 4 (32-channel slices: pix2pix / VAE
+// widths; the fifth chunk of the 80-byte patch pixel is padding).  PIECES: 1 KiB pieces per patch buffer.  Row tiles are whole
+// images or -- IgClass.nbh * nbw > 1 -- BLOCKS of one image (bh x bw anchors, rows in block-major order) whose patch carries a
+// halo of `halo` lattice pixels on every side (out-of-image halo pixels are out-of-range sources = zeros: every tap of every
+// row reads inside its patch).
+template <int BM, int BN, int ABL, int CK = PT_CK, int PIECES = PT_PIECES>
 __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs args) {
   using T = bf16_t;
   constexpr int NTHR = 512, CW = 4, LW = 4;
+  constexpr int PATCHB = PIECES * 1024, PPW = (PIECES + LW - 1) / LW, PPW0 = (PPW + 1) / 2;     // pieces per loader wave and patch; of them in the first of its two steps
   constexpr int WMR = BM / CW, TM = WMR / 16, TN = BN / 16;
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;      // filter rows kept per stage (whole 8-row piece pairs)
   constexpr int NIB = BNL / 8, NBJ = (NIB + LW - 1) / LW;
   constexpr int STAGE = BNL * IG_BKB, NS = 3;
-  constexpr int NPL = NBJ + PT_APS;                       // pieces per loader wave and step
-  static_assert(NPL == 9, "the counted waits below are written for 7 filter + 2 patch pieces");
-  static_assert(BM % (16 * CW) == 0 && BN % 16 == 0, "tile config");
+  static_assert(PIECES % LW == 0, "patch pieces are dealt evenly to the loader waves");
+  static_assert(BM % (16 * CW) == 0 && BN % 16 == 0 && BN / 16 >= BM / (16 * CW), "tile config: the K step hands out one A fragment per column tile");
   // LDS map: [zero pixel + dummy landing zones | filter ring | patches | chunk table | bias row].  The zero pixel sits at
   // byte 0, so "this tap is outside the image" is an AND of the fragment address with 0.
-  constexpr int OFF_ZERO = 0, OFF_RING = PT_ZEROB, OFF_PATCH = OFF_RING + NS * STAGE, OFF_TAB = OFF_PATCH + PT_NPB * PT_PATCHB;
+  constexpr int OFF_ZERO = 0, OFF_RING = PT_ZEROB, OFF_PATCH = OFF_RING + NS * STAGE, OFF_TAB = OFF_PATCH + PT_NPB * PATCHB;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1232,7 +1255,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
   const bool is_mma = wave < CW;
   const int ntaps = cl.ntaps, G = cl.ngroups, QH = cl.QH, QW = cl.QW;
   const int GHW = cl.GH * cl.GW;
-  const int SLC = ntaps * PT_CK;                       // chunks per slice
+  const int SLC = ntaps * CK;                          // chunks per slice
+  const int halo = cl.halo;
   const int P = args.nslices * G;                      // phases
 
   unsigned long long ph0 = 0, ph1 = 0, php = 0, t0 = 0, t1 = 0, t2 = 0, s_issue = 0, s_mma = 0, s_sync = 0;   // stamps (diagnostic build only)
@@ -1279,7 +1303,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
     for (int g0 = 0; g0 < nsteps * 8; g0 += 64 * CW) {
       const int g = g0 + tid;
       const unsigned u = fd_div((unsigned)g, args.fd_ck);
-      const int j = g - (int)u * PT_CK;
+      const int j = g - (int)u * CK;
       const unsigned sl = fd_div(u, cl.fd_nt);
       const int t = (int)(u - sl * (unsigned)ntaps);
       const int tv = __builtin_amdgcn_ds_bpermute((t & 31) << 2, tapvec);
@@ -1288,7 +1312,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
         const int gi = tv & 15, dhq = ((tv >> 4) & 15) - 8, dwq = ((tv >> 8) & 15) - 8;
         const int p = (int)sl * G + gi;
         const int buf = p - (p / PT_NPB) * PT_NPB;
-        w0 = OFF_PATCH + buf * PT_PATCHB + (dhq * QW + dwq) * PT_PIXB + j * 16;
+        w0 = OFF_PATCH + buf * PATCHB + (dhq * QW + dwq) * PT_PIXB + j * 16;
         w1 = t;
       }
       if (g < nsteps * 8) {
@@ -1342,42 +1366,55 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       if (++x.gi == G) { x.gi = 0; ++x.sl; }
       x.buf = x.buf == PT_NPB - 1 ? 0 : x.buf + 1;
     };
-    auto ph_end_chunk = [&](const Ph& x) { return x.sl * SLC + (cl.grp[x.gi].t0 + cl.grp[x.gi].nt) * PT_CK; };
-    auto ph_delta = [&](const Ph& x) { return (unsigned)(((cl.grp[x.gi].ph * args.SW + cl.grp[x.gi].pw) * args.Cs + x.sl * PT_CK * 8) * 2); };
+    auto ph_end_chunk = [&](const Ph& x) { return x.sl * SLC + (cl.grp[x.gi].t0 + cl.grp[x.gi].nt) * CK; };
+    auto ph_delta = [&](const Ph& x) { return (unsigned)(((cl.grp[x.gi].ph * args.SW + cl.grp[x.gi].pw) * args.Cs + x.sl * CK * 8) * 2); };
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's table / zero-pixel stores are done before any LDS-DMA is pending
     // ---- prologue: ring stage 0 first (its lane constants are cheap), the first patch, then what step 0 does not read yet
     // (patches 1 and 2, ring stage 1), which stays in flight across the prologue barrier: the wait of step 0 covers it
     b_pieces(0);
     // patch pieces: piece ps * 4 + lwave of a patch, 64 consecutive 16-byte chunks of its [pixel][PT_CK] image
-    const int IPT = BM / GHW;                          // images per row tile
+    const int IPT = BM / GHW;                          // images (or blocks) per row tile
     const int nimg = M / GHW;
-    unsigned a_src[PT_PIECES / LW];
+    const int nblk = cl.nbh * cl.nbw;                   // blocks per image (1: whole-image tiles)
+    const int LH = args.SH / args.sigma, LW_ = args.SW / args.sigma;      // the source's sub-lattice
+    unsigned a_src[PPW];
 #pragma unroll
-    for (int ps = 0; ps < PT_PIECES / LW; ++ps) {
+    for (int ps = 0; ps < PPW; ++ps) {
       const int c = (ps * LW + lwave) * 64 + lane;
       const int pl = c / PT_CK, j = c - pl * PT_CK;
       const unsigned il = fd_div((unsigned)pl, cl.fd_qhw);
       const int rem = pl - (int)il * QH * QW;
       const int qh = (int)fd_div((unsigned)rem, cl.fd_qw), qw = rem - qh * QW;
-      const int img = tile_m * IPT + (int)il;
-      const bool ok = (int)il < IPT && img < nimg;
-      a_src[ps] = ok ? (unsigned)((((img * args.SH + args.sigma * qh) * args.SW + args.sigma * qw) * args.Cs + j * 8) * 2) : OOB_OFFSET;
+      const int blk = tile_m * IPT + (int)il;
+      bool ok = (int)il < IPT && blk < nimg && j < CK;
+      int img = blk, lh = qh, lw = qw;
+      if (nblk > 1) {                                  // block tiles: lattice pixel = block origin - halo + (qh, qw)
+        img = blk / nblk;
+        const int br = blk - img * nblk, bi = br / cl.nbw, bj = br - bi * cl.nbw;
+        lh = bi * cl.GH - halo + qh;
+        lw = bj * cl.GW - halo + qw;
+        ok = ok && (unsigned)lh < (unsigned)LH && (unsigned)lw < (unsigned)LW_;
+      }
+      a_src[ps] = ok ? (unsigned)((((img * args.SH + args.sigma * lh) * args.SW + args.sigma * lw) * args.Cs + j * 8) * 2) : OOB_OFFSET;
     }
     auto a_piece = [&](const Ph& x, unsigned delta, auto ps_c) {
       constexpr int ps = decltype(ps_c)::value;
       const unsigned off = a_src[ps] == OOB_OFFSET ? OOB_OFFSET : a_src[ps] + delta;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(smem + OFF_PATCH + x.buf * PT_PATCHB + (ps * LW + lwave) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_ptr_t)(smem + OFF_PATCH + x.buf * PATCHB + (ps * LW + lwave) * 1024), 16, off, 0, 0, 0);
+    };
+    auto a_pieces = [&](const Ph& x, unsigned delta, auto lo_c, auto hi_c) {       // pieces [lo, hi) of this wave's share of a patch
+      static_for<decltype(lo_c)::value, decltype(hi_c)::value>([&](auto ps_c) { a_piece(x, delta, ps_c); });
     };
     Ph pn{0, 0, 0};
     {
       const unsigned dl0 = ph_delta(pn);
-      a_piece(pn, dl0, IntC<0>{}); a_piece(pn, dl0, IntC<1>{}); a_piece(pn, dl0, IntC<2>{}); a_piece(pn, dl0, IntC<3>{});
+      a_pieces(pn, dl0, IntC<0>{}, IntC<PPW>{});
       ph_next(pn);
     }
     b_pieces(1);
     TDG_STAMP(t0);
     s_mma = t0 - ph0;                                    // (stamps: kernel entry -> prologue pieces issued)
-    asm volatile("s_waitcnt vmcnt(7)" ::: "memory");       // stage 0 and patch 0 have landed; stage 1 stays in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NBJ) : "memory");       // stage 0 and patch 0 have landed; stage 1 stays in flight
     __builtin_amdgcn_s_barrier();
     TDG_STAMP(php);
     // Patches 1 and 2 are loaded whole (4 pieces per wave) in steps 0 and 1 -- their buffers are free, and with every
@@ -1401,15 +1438,15 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
       if constexpr (ABL == 4) {
       } else if (step < PT_NPB - 1) {
         if (left > 0) {
-          a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{}); a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
+          a_pieces(pn, dl, IntC<0>{}, IntC<PPW>{});
           ph_next(pn);
           --left;
           dl = left > 0 ? ph_delta(pn) : 0u;
         }
       } else if (step == ready) {
-        a_piece(pn, dl, IntC<0>{}); a_piece(pn, dl, IntC<1>{});
+        a_pieces(pn, dl, IntC<0>{}, IntC<PPW0>{});
       } else if (step == ready + 1) {
-        a_piece(pn, dl, IntC<2>{}); a_piece(pn, dl, IntC<3>{});
+        a_pieces(pn, dl, IntC<PPW0>{}, IntC<PPW>{});
         ph_next(pn);
         ph_next(pf);
         --left;
@@ -1437,7 +1474,7 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
         const int rem = loc - (int)il * GHW;
         a_i[i] = (int)fd_div((unsigned)rem, cl.fd_gw);
         b_i[i] = rem - a_i[i] * cl.GW;
-        base_i[i] = (((int)il * QH + a_i[i]) * QW + b_i[i]) * PT_PIXB;
+        base_i[i] = (((int)il * QH + a_i[i] + halo) * QW + b_i[i] + halo) * PT_PIXB;
         rowbits[i] = colbits[i] = 0u;
       }
       // validity mask = (taps whose row offset keeps the row inside the lattice) & (the same for columns): per distinct
@@ -1450,8 +1487,8 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
         if (tr | tc) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) {
-            rowbits[i] |= (unsigned)(a_i[i] + d) < (unsigned)QH ? tr : 0u;
-            colbits[i] |= (unsigned)(b_i[i] + d) < (unsigned)QW ? tc : 0u;
+            rowbits[i] |= (unsigned)(a_i[i] + halo + d) < (unsigned)QH ? tr : 0u;
+            colbits[i] |= (unsigned)(b_i[i] + halo + d) < (unsigned)QW ? tc : 0u;
           }
         }
       }
@@ -1999,13 +2036,6 @@ struct WdLoader {
 #ifndef TDG_WG_ABLATE
 #define TDG_WG_ABLATE 0
 #endif
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(IntC<I>{});
-    static_for<I + 1, N>(f);
-  }
-}
 
 template <int BN, int MODE>
 __global__ void __launch_bounds__(512, 2) igemm_wgrad_dma_kernel(const WgArgs args) {
@@ -3075,31 +3105,34 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
 }
 
 // igemm_fwd_patch_kernel: does it apply to this launch?  Fills the tap groups / lattice of every class when it does.
-// Conditions (each one is what the kernel's indexing assumes): bf16 vector gather, 5-chunk K slices, 208-column tiles with
-// the staged epilogue, row tiles of whole images, a source whose sub-lattices all have the same [QH, QW] shape, patches of
-// <= PT_MAXPIX pixels, tap groups in K order, and a phase schedule in which every patch lands two steps before its first
-// read (the loader's own rule, simulated here).
-template <int BM>
+// Conditions (each one is what the kernel's indexing assumes): bf16 vector gather, CK-chunk K slices, BN-column tiles with
+// the staged epilogue, row tiles of whole images OR of one bh x bw block of an image's anchor grid (then the classes' GH, GW,
+// fd_ghw, fd_gw are rewritten to the block's and nbh, nbw, halo set -- only when the whole plan holds), a source whose
+// sub-lattices all have the same shape, patches that fit PIECES KiB, tap groups in K order, and a phase schedule in which
+// every patch lands two steps before its first read (the loader's own rule, simulated here).
+template <int BM, int BN = 208, int CK = PT_CK, int PIECES = PT_PIECES>
 bool plan_fwd_patch(IgArgs& a, int mmax) {
   const int enabled = getenv("TDG_PATCH") ? atoi(getenv("TDG_PATCH")) : 1;     // diagnostics: 0 = igemm_fwd_dma_kernel, 2 = also on small grids
-  if (!enabled || (int)a.fd_ck.d != PT_CK || a.accumulate || (a.N & 3) || (a.Cso & 3)) return false;
+  if (!enabled || (int)a.fd_ck.d != CK || a.accumulate || (a.N & 3) || (a.Cso & 3)) return false;
   if (a.sigma < 1 || a.sigma > 2 || a.SH % a.sigma || a.SW % a.sigma) return false;
-  const int QH = a.SH / a.sigma, QW = a.SW / a.sigma;
-  if (QW > 32 || QH > 64) return false;
-  if (enabled != 2 && (long long)tdg_ceil_div(mmax, BM) * tdg_ceil_div(a.N, 208) * a.nclasses < 160) return false;   // small grids: the 112-column forms
+  const int LH = a.SH / a.sigma, LWd = a.SW / a.sigma;        // the source's sub-lattice
+  if (enabled != 2 && (long long)tdg_ceil_div(mmax, BM) * tdg_ceil_div(a.N, BN) * a.nclasses < 160) return false;   // small grids: the 112-column forms
+  struct Geo { int bh, bw, nbh, nbw, halo, QH, QW; } geo[IG_MAX_CLASSES];
   for (int ci = 0; ci < a.nclasses; ++ci) {
     IgClass& c = a.cls[ci];
+    if (c.nbh * c.nbw > 1) return false;                       // (already rewritten: a plan is made once per launch)
     const int ghw = c.GH * c.GW;
-    if (ghw <= 0 || BM % ghw || c.M % ghw) return false;
-    if ((BM / ghw) * QH * QW > PT_MAXPIX || c.GH > QH + 8 || c.GW > QW + 8) return false;
+    if (ghw <= 0 || c.M % ghw) return false;
     if (c.nsteps < 4 || c.nsteps * 64 > 16384 || c.ntaps > 31) return false;
-    // tap groups: consecutive taps with equal (dh mod sigma, dw mod sigma)
-    int ng = 0;
+    // tap groups: consecutive taps with equal (dh mod sigma, dw mod sigma); the lattice offsets of the taps
+    int ng = 0, dmax = 0;
     for (int t = 0; t < c.ntaps; ++t) {
       const int dh = (signed char)(c.tap[t] & 0xff), dw = (signed char)((c.tap[t] >> 8) & 0xff);
       const int ph = ((dh % a.sigma) + a.sigma) % a.sigma, pw = ((dw % a.sigma) + a.sigma) % a.sigma;
       const int dhq = (dh - ph) / a.sigma, dwq = (dw - pw) / a.sigma;
-      if (dhq < -8 || dhq > 7 || dwq < -8 || dwq > 7 || dhq * QW + dwq < -127 || dhq * QW + dwq > 127) return false;
+      if (dhq < -8 || dhq > 7 || dwq < -8 || dwq > 7) return false;
+      dmax = abs(dhq) > dmax ? abs(dhq) : dmax;
+      dmax = abs(dwq) > dmax ? abs(dwq) : dmax;
       if (ng && c.grp[ng - 1].ph == ph && c.grp[ng - 1].pw == pw) { ++c.grp[ng - 1].nt; continue; }
       for (int g = 0; g < ng; ++g)
         if (c.grp[g].ph == ph && c.grp[g].pw == pw) return false;     // a group split in two: not the K order this kernel wants
@@ -3107,12 +3140,29 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
       c.grp[ng].t0 = t; c.grp[ng].nt = 1; c.grp[ng].ph = ph; c.grp[ng].pw = pw;
       ++ng;
     }
-    c.ngroups = ng; c.QH = QH; c.QW = QW;
-    c.fd_qhw = make_fastdiv(QH * QW); c.fd_qw = make_fastdiv(QW);
+    c.ngroups = ng;
+    Geo& g = geo[ci];
+    if (BM % ghw == 0) {                                       // whole images: the patch is the image's sub-lattice, taps outside it are masked
+      g = Geo{c.GH, c.GW, 1, 1, 0, LH, LWd};
+    } else {                                                   // a block of one image with a halo of dmax lattice pixels
+      int bw = c.GW < 16 ? c.GW : 16;
+      while (bw > 1 && (c.GW % bw || BM % bw)) --bw;
+      const int bh = BM / bw;
+      if (bh * bw != BM || c.GH % bh || c.GW % bw) return false;
+      g = Geo{bh, bw, c.GH / bh, c.GW / bw, dmax, bh + 2 * dmax, bw + 2 * dmax};
+    }
+    if (g.QW > 32 || g.QH > 64) return false;
+    if ((BM / (g.bh * g.bw)) * g.QH * g.QW * PT_PIXB > PIECES * 1024 || g.bh > g.QH + 8 || g.bw > g.QW + 8) return false;
+    for (int t = 0; t < c.ntaps; ++t) {
+      const int dh = (signed char)(c.tap[t] & 0xff), dw = (signed char)((c.tap[t] >> 8) & 0xff);
+      const int ph = ((dh % a.sigma) + a.sigma) % a.sigma, pw = ((dw % a.sigma) + a.sigma) % a.sigma;
+      const int off = ((dh - ph) / a.sigma) * g.QW + (dw - pw) / a.sigma;
+      if (off < -127 || off > 127) return false;
+    }
     // the loader's schedule: phase p (>= PT_NPB) is issued in steps s_p, s_p + 1 and is visible from step s_p + 3
-    const int P = a.nslices * ng, slc = c.ntaps * PT_CK;
-    auto first_chunk = [&](int p) { return (p / ng) * slc + c.grp[p % ng].t0 * PT_CK; };
-    auto end_chunk = [&](int p) { return (p / ng) * slc + (c.grp[p % ng].t0 + c.grp[p % ng].nt) * PT_CK; };
+    const int P = a.nslices * ng, slc = c.ntaps * CK;
+    auto first_chunk = [&](int p) { return (p / ng) * slc + c.grp[p % ng].t0 * CK; };
+    auto end_chunk = [&](int p) { return (p / ng) * slc + (c.grp[p % ng].t0 + c.grp[p % ng].nt) * CK; };
     // patches 1 .. PT_NPB - 1 go out whole in steps 0 .. PT_NPB - 2 (visible to the reads of step issue + 2)
     for (int p = 1; p < PT_NPB && p < P; ++p)
       if (first_chunk(p) / 8 < (p - 1) + 2) return false;
@@ -3124,10 +3174,21 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
       prev_issue = issue;
     }
   }
+  for (int ci = 0; ci < a.nclasses; ++ci) {                    // the plan holds: commit the geometry
+    IgClass& c = a.cls[ci];
+    const Geo& g = geo[ci];
+    c.QH = g.QH; c.QW = g.QW;
+    c.fd_qhw = make_fastdiv(g.QH * g.QW); c.fd_qw = make_fastdiv(g.QW);
+    c.nbh = g.nbh; c.nbw = g.nbw; c.halo = g.halo;
+    if (g.nbh * g.nbw > 1) {
+      c.GH = g.bh; c.GW = g.bw;
+      c.fd_ghw = make_fastdiv(g.bh * g.bw); c.fd_gw = make_fastdiv(g.bw);
+    }
+  }
   return true;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int CK = PT_CK, int PIECES = PT_PIECES>
 int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   a.n_begin = 0;
   a.ntiles_n = tdg_ceil_div(a.N, BN);
@@ -3147,22 +3208,28 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   int smax = 0;
   for (int c = 0; c < a.nclasses; ++c) smax = a.cls[c].nsteps > smax ? a.cls[c].nsteps : smax;
   constexpr int BNL = 2 * ((BN / 16 + 1) / 2) * 16;
-  const size_t lds = PT_ZEROB + 3 * (size_t)BNL * IG_BKB + PT_NPB * PT_PATCHB + (size_t)smax * 64 + BNL * sizeof(float);
+  const size_t lds = PT_ZEROB + 3 * (size_t)BNL * IG_BKB + PT_NPB * (size_t)PIECES * 1024 + (size_t)smax * 64 + BNL * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 0, CK, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef TDG_STAMPS
     if constexpr (BM == 192) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_patch_kernel<BM, BN, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
+#endif
     attr_set = true;
   }
   static char name[64] = "";
   if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_patch_kernel<bf16,%d,%d>", BM, BN);
   tdg_note_kernel(name);
   dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  if (lds > 160 * 1024) {
+    tdg_set_error("igemm_fwd_patch: %zu bytes of LDS", lds);
+    return TDG_EUNSUPPORTED;
+  }
   tdg_timing_start(name, t_flops, s);
 #ifdef TDG_STAMPS
   // ablation instantiations (their results are garbage): compiled into the diagnostic library (build.sh stamps) only
@@ -3174,10 +3241,10 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
     else if (abl == 4) hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 4>), grid, block, lds, s, a);
     else hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
   } else {
-    hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
+    hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0, CK, PIECES>), grid, block, lds, s, a);
   }
 #else
-  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0>), grid, block, lds, s, a);
+  hipLaunchKernelGGL((igemm_fwd_patch_kernel<BM, BN, 0, CK, PIECES>), grid, block, lds, s, a);
 #endif
   tdg_timing_stop(s);
   TDG_HIP_LAUNCH_CHECK("igemm_fwd_patch");
@@ -3271,6 +3338,15 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   }
   // 128-column problems (pix2pix / VAE widths 128, 256, 512, 1024) and 65..112 columns (the generator's 100-channel
   // layers, a 7-tile-wide column tile): the same LDS-DMA kernel, 3-stage ring at every row tile
+  // 128- / 64-column problems whose K runs in 32-channel slices (pix2pix / VAE widths): 256-row tiles = four whole images or
+  // one 16 x 16 block of an image, the gathered operand resident in LDS patches (igemm_fwd_patch_kernel<256, 128 | 64, 4-chunk
+  // slices, 28 KiB patches>): 16 + 13 KB (128 columns) / 8 + 13 KB (64) of intake per K step instead of 16 + 32 / 8 + 16
+  if constexpr (sizeof(T) == 2) {
+    if (veca && dma_mode == 1 && (bn == 128 || bn == 64) && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW")) {
+      if (bn == 128 && a.N > 112 && plan_fwd_patch<256, 128, 4, 28>(a, mmax)) return launch_fwd_patch<256, 128, 4, 28>(a, mmax, s);
+      if (bn == 64 && a.N > 32 && plan_fwd_patch<256, 64, 4, 28>(a, mmax)) return launch_fwd_patch<256, 64, 4, 28>(a, mmax, s);
+    }
+  }
   if (veca && bn == 128 && dma_mode && (a.N & 3) == 0 && (a.Cso & 3) == 0) {
     const int bnt = a.N <= 112 ? 112 : 128;
     const long long per = (long long)tdg_ceil_div(a.N, bnt) * a.nclasses;
@@ -3387,10 +3463,19 @@ inline int eff_channels(int c, int cs, int vec) {
 // 5-chunk slices (C / 8 a multiple of 5: the GAN's 200 / 400 / 800 channels) are what igemm_fwd_patch_kernel keeps resident in
 // LDS -- 80-byte pixels, an odd number of 16-byte chunks, so its fragment reads spread over all banks; every other
 // forward-type kernel reads the sliced order through k_decode.  cv: chunks per tap.  Returns cv for the plain order.
-inline int k_slice_chunks(int dtype, int cv) {
+// nrows: the GEMM's columns (rows of the packed operand): the 4-chunk order is for igemm_fwd_patch_kernel's 128- / 64-column
+// tiles only (a one-column problem keeps the plain order conv_n1_fwd_kernel reads).
+inline int k_slice_chunks(int dtype, int cv, int nrows) {
   static const int enabled = getenv("TDG_KSLICE") ? atoi(getenv("TDG_KSLICE")) : 1;   // diagnostics: 0 = plain order everywhere
-  if (!enabled || dtype != TDG_BF16 || cv < 5 || cv % 5 != 0) return cv;
-  return 5;
+  if (!enabled || dtype != TDG_BF16) return cv;
+  if (cv >= 5 && cv % 5 == 0) return 5;
+  // 32-channel slices (pix2pix / VAE widths, 64 ... 1024 channels) for the block-tile form of igemm_fwd_patch_kernel: opt-in
+  // (TDG_BLOCKPATCH=1, read per call: the variant tests set it before they build their convs).  Measured in round 4 on
+  // pix2pix bs 64: the block-patch kernel takes 5.87 ms where the slab kernel takes 5.34 (and the slab kernel itself loses
+  // 4 % on the sliced K order): those layers run 16 - 64 K steps per workgroup and spend as long in prologue + epilogue as in
+  // the loop, so less intake per step buys nothing.
+  if (cv >= 8 && cv % 4 == 0 && nrows > 32 && getenv("TDG_BLOCKPATCH") && atoi(getenv("TDG_BLOCKPATCH")) == 1) return 4;
+  return cv;
 }
 
 // K order of the forward filter's taps.  Stride 2: the taps of one (kh & 1, kw & 1) parity class read the same quarter
@@ -3652,7 +3737,7 @@ static void build_pack_fwd(const TdgConvDesc* d, const float* w, void* packed, P
   a->ntaps = d->kh * d->kw;
   a->C = d->c;
   a->Ceff = ce;
-  a->CK = (ce % vec == 0 && eff_channels(d->c, d->cs, vec)) ? k_slice_chunks(d->dtype, ce / vec) * vec : ce;
+  a->CK = (ce % vec == 0 && eff_channels(d->c, d->cs, vec)) ? k_slice_chunks(d->dtype, ce / vec, d->k) * vec : ce;
   a->Kp = (int)tdg_round_up((long long)a->ntaps * ce, bke);
   a->stride_tap = d->c * d->k;
   a->stride_row = 1;       // row = small-side channel (last master index)
@@ -3680,7 +3765,7 @@ static int build_pack_bwd(const TdgConvDesc* d, const float* w, void* packed, Pa
     a.ntaps = cls[i].ntaps;
     a.C = d->k;
     a.Ceff = ke;
-    a.CK = (ke % vec == 0 && eff_channels(d->k, d->ks, vec)) ? k_slice_chunks(d->dtype, ke / vec) * vec : ke;
+    a.CK = (ke % vec == 0 && eff_channels(d->k, d->ks, vec)) ? k_slice_chunks(d->dtype, ke / vec, d->c) * vec : ke;
     a.Kp = (int)tdg_round_up((long long)a.ntaps * ke, bke);
     a.stride_tap = d->c * d->k;
     a.stride_row = d->k;    // row = big-side channel
@@ -3921,7 +4006,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
     return TDG_OK;
   }
   static const int n1_enabled = getenv("TDG_CONVN1") ? atoi(getenv("TDG_CONVN1")) : 1;   // diagnostics: 0 = the 128 x 16 MFMA tile
-  if (n1_enabled && d->k == 1 && veca && k_slice_chunks(d->dtype, C / vec) == C / vec && d->kh * d->kw <= IG_MAX_TAPS && (long long)n_images * d->oh * d->ow >= 1024 &&
+  if (n1_enabled && d->k == 1 && veca && k_slice_chunks(d->dtype, C / vec, d->k) == C / vec && d->kh * d->kw <= IG_MAX_TAPS && (long long)n_images * d->oh * d->ow >= 1024 &&
       !(epi && (epi->accumulate || epi->mask_mode != TDG_MASK_NONE))) {
     if (epi && epi->col_nblk_out) *epi->col_nblk_out = 0;       // no column partials from this kernel: the host runs its own pass
     ConvN1Args f;
@@ -3962,7 +4047,7 @@ int tdg_conv2d_fwd(const TdgConvDesc* d, int n_images, const void* x, const void
   a.SH = d->h; a.SW = d->w; a.sigma = d->stride;
   a.C = C; a.Cs = d->cs;
   a.fd_c = make_fastdiv(veca ? C / vec : C);
-  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec) : C);
+  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec, d->k) : C);
   a.nslices = (int)(a.fd_c.d / a.fd_ck.d);
   a.N = d->k; a.OH = d->oh; a.OW = d->ow; a.os = 1; a.Cso = d->ks;
   a.nclasses = 1;
@@ -4091,7 +4176,7 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
   a.SH = d->oh; a.SW = d->ow; a.sigma = 1;
   a.C = C; a.Cs = d->ks;
   a.fd_c = make_fastdiv(veca ? C / vec : C);
-  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec) : C);
+  a.fd_ck = make_fastdiv(veca ? k_slice_chunks(d->dtype, C / vec, d->c) : C);
   a.nslices = (int)(a.fd_c.d / a.fd_ck.d);
   a.N = d->c; a.OH = d->h; a.OW = d->w; a.os = d->stride; a.Cso = d->cs;
   BwdClassPlan plan[IG_MAX_CLASSES];

@@ -205,6 +205,49 @@ def test_conv_patch_resident_kernel(case, monkeypatch):
     assert 'igemm_fwd_patch_kernel' in pkg('_lib').load().tdg_last_kernel().decode()
 
 
+BLOCK_PATCH_CASES = [
+    # n, h, w, cin, cout, k, stride, forward dispatch expected
+    (2, 64, 64, 64, 128, 4, 2, '256,128'),     # pix2pix e2 at quarter size: 32 x 32 outputs = four 16 x 16 blocks per image; bwd-data: 64 columns
+    (3, 32, 32, 128, 256, 4, 2, '256,128'),    # e3: one block per image, two column tiles
+    (5, 16, 16, 256, 512, 4, 2, '256,128'),    # e4 at 8 x 8 outputs: WHOLE-image tiles (four images), ragged last tile; bwd-data: blocks
+    (2, 64, 64, 64, 128, 5, 2, '256,128'),     # VAE c2 geometry (5 x 5, stride 2): tap groups of 9 / 6 / 6 / 4, halo 1
+    (2, 32, 32, 64, 128, 3, 1, '256,128'),     # stride 1: one tap group, blocks with a halo on every side
+    (2, 128, 128, 64, 64, 4, 2, '256,64'),     # 64-column tiles both ways (d7-like widths)
+    (2, 48, 32, 64, 128, 4, 2, None),          # 24 x 16 outputs: no 16 x 16 blocks -> the slab kernel (plan refused)
+]
+
+
+@pytest.mark.parametrize('case', BLOCK_PATCH_CASES)
+def test_conv_block_patch_kernel(case, monkeypatch):
+    """igemm_fwd_patch_kernel<256, 128 | 64> (32-channel K slices, 28 KiB patches): row tiles of one 16 x 16 block of an image
+    with a halo'd patch, or of four whole images, forced onto small problems; forward, backward-data and filter gradient
+    against the oracle (the filter gradient runs on the 4-chunk K order of the packed operand), dispatch asserted, a second
+    launch bit-equal."""
+    K = pkg('kernels')
+    monkeypatch.setenv('TDG_PATCH', '2')
+    monkeypatch.setenv('TDG_BLOCKPATCH', '1')    # (opt-in: on pix2pix / VAE the slab kernel is the faster one; DESIGN.md section 4)
+    n, h, w, cin, cout, k, s, want = case
+    test_conv_fwd_bwd((n, h, w, cin, cout, k, s), 1)
+    dev = torch.device('cuda:0')
+    oh, pt, _ = T.same_pad(h, k, s)
+    ow, pl, _ = T.same_pad(w, k, s)
+    big, small = K.Act(n, h, w, cin, K.BF16, dev), K.Act(n, oh, ow, cout, K.BF16, dev)
+    conv = K.Conv(big, small, k, k, s, pt, pl)
+    rng = np.random.default_rng(3)
+    conv.pack(torch.tensor(rng.standard_normal((k, k, cin, cout)).astype(np.float32) * 0.05, device=dev))
+    big.set(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    conv.fwd(big.ptr(), small.ptr(), n)
+    kern = pkg('_lib').load().tdg_last_kernel().decode()
+    if want is None:
+        assert 'igemm_fwd_patch_kernel' not in kern, kern
+    else:
+        assert 'igemm_fwd_patch_kernel<bf16,%s>' % want in kern, kern
+    first = small.get().copy()
+    small.set(np.zeros_like(first))
+    conv.fwd(big.ptr(), small.ptr(), n)
+    assert np.array_equal(small.get(), first)
+
+
 WGRAD_PATCH_CASES = [
     (7, 16, 16, 200, 400, 5, 2),      # c2 geometry: one image per 64-row step, 25 slices, 20 K tiles of 32 (slice, tap) units
     (25, 8, 8, 400, 800, 5, 2),       # c3: four images per step, ragged last step (25 images), four column tiles
