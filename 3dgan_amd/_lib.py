@@ -119,6 +119,8 @@ SIGNATURES = {
     'tdg_png_unfilter': (_i, [C.c_char_p, _i, _i, _i, _vp]),
     'tdg_jpeg_info': (_i, [C.c_char_p, _sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'tdg_jpeg_decode': (_i, [C.c_char_p, _sz, _vp, _sz]),
+    'tdg_shuffle_draw': (_i, [_vp, C.c_int64, _vp, _vp, C.c_int64, C.c_int64, _vp]),
+    'tdg_gather_rows': (_i, [_vp, C.c_int64, _sz, _vp, C.c_int64, _vp]),
 }
 
 _lib = None

@@ -111,6 +111,11 @@ def build_parser():
     add('--resize', type=int, nargs=2, help='Resize input images to w x h.')
     add('--shuffle', default=True, action='store_true')
     add('--buffer_size', type=int, default=10000)
+    add('--streaming', default=False, action='store_true',
+        help='Keep the dataset in host memory and serve it through the reference\'s pipeline shape (repeat -> shuffle(buffer_size) -> '
+             'batch over a pinned-host ring with asynchronous copies) even when it fits the HBM budget.')
+    add('--hbm_budget_gb', type=float, default=64.0,
+        help='Datasets whose float32 form is larger than this stay in host memory (streaming input pipeline).')
     add('--grayscale', default=False, action='store_true')
     add('--cache_dir', default=None, help='Cache decoded datasets here.')
     add('--data_dir', default='data', help='gen-1: where the dataset files live (data.py:37-39).')

@@ -2,6 +2,7 @@
 // TensorFlow's C++ `tf.image.decode_png`, hem/data/nyuv2.py:152-153; floorplans: data.py:15).  No device code here.
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "../../include/tdg.h"
 
@@ -450,5 +451,61 @@ extern "C" int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigne
   }
   for (int i = 0; i < d.ncomp; ++i) if (own[i]) free(full[i]);
   cleanup();
+  return TDG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Shuffle buffer over example indices + batch assembly (include/tdg.h: tdg_shuffle_draw / tdg_gather_rows).
+namespace {
+inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+inline uint64_t xoshiro_next(uint64_t* s) {
+  const uint64_t r = rotl64(s[1] * 5, 7) * 9, t = s[1] << 17;
+  s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+  s[2] ^= t;
+  s[3] = rotl64(s[3], 45);
+  return r;
+}
+// uniform in [0, n): Lemire's multiply-shift with rejection (unbiased)
+inline uint64_t uniform_below(uint64_t* s, uint64_t n) {
+  uint64_t x = xoshiro_next(s);
+  __uint128_t m = (__uint128_t)x * n;
+  uint64_t lo = (uint64_t)m;
+  if (lo < n) {
+    const uint64_t t = (0 - n) % n;
+    while (lo < t) {
+      x = xoshiro_next(s);
+      m = (__uint128_t)x * n;
+      lo = (uint64_t)m;
+    }
+  }
+  return (uint64_t)(m >> 64);
+}
+}  // namespace
+
+extern "C" int tdg_shuffle_draw(int64_t* buf, int64_t buf_len, uint64_t* state, int64_t* next_in, int64_t n_total, int64_t count,
+                                int64_t* out) {
+  if (!buf || !state || !next_in || !out || buf_len < 1 || n_total < 1 || count < 0 || *next_in < 0 || *next_in >= n_total) {
+    tdg_set_error("tdg_shuffle_draw: bad argument (buf_len %lld, n_total %lld, count %lld)", (long long)buf_len, (long long)n_total, (long long)count);
+    return TDG_EINVAL;
+  }
+  if (!(state[0] | state[1] | state[2] | state[3])) { tdg_set_error("tdg_shuffle_draw: the all-zero generator state is invalid"); return TDG_EINVAL; }
+  int64_t nx = *next_in;
+  for (int64_t i = 0; i < count; ++i) {
+    const int64_t j = (int64_t)uniform_below(state, (uint64_t)buf_len);
+    out[i] = buf[j];
+    buf[j] = nx;
+    nx = nx + 1 == n_total ? 0 : nx + 1;
+  }
+  *next_in = nx;
+  return TDG_OK;
+}
+
+extern "C" int tdg_gather_rows(const unsigned char* src, int64_t n_rows, size_t row_bytes, const int64_t* idx, int64_t count,
+                               unsigned char* out) {
+  if (!src || !idx || !out || n_rows < 1 || count < 0) { tdg_set_error("tdg_gather_rows: bad argument"); return TDG_EINVAL; }
+  for (int64_t i = 0; i < count; ++i) {
+    if (idx[i] < 0 || idx[i] >= n_rows) { tdg_set_error("tdg_gather_rows: index %lld outside [0, %lld)", (long long)idx[i], (long long)n_rows); return TDG_EINVAL; }
+    memcpy(out + (size_t)i * row_bytes, src + (size_t)idx[i] * row_bytes, row_bytes);
+  }
   return TDG_OK;
 }

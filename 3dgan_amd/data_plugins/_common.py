@@ -2,7 +2,7 @@
 import numpy as np
 import torch
 
-from ..data import ArraySource
+from ..data import ArraySource, StreamingSource
 
 
 def resize_bilinear_tf1(x, out_h, out_w):
@@ -30,6 +30,23 @@ def finish_images(imgs_u8, args, sess, pad_to_32=False):
     this replica's shard (rank r takes every world_size-th example: ops/input.py:24 on a shuffled stream)."""
     import torch.nn.functional as F
     n = imgs_u8.shape[0]
+    # a dataset whose float32 form exceeds the HBM budget (or --streaming) stays in host memory and is served by the reference's
+    # own pipeline shape: repeat -> shuffle(buffer_size) -> batch(B * n_gpus) over a pinned-host ring (data.StreamingSource)
+    budget = float(getattr(args, 'hbm_budget_gb', 64.0) or 64.0) * (1 << 30)
+    if getattr(args, 'streaming', False) or float(np.prod(imgs_u8.shape)) * 4.0 > budget:
+        def post(x):
+            if pad_to_32 and x.shape[1] == 28:
+                x = F.pad(x.permute(0, 3, 1, 2), (2, 2, 2, 2)).permute(0, 2, 3, 1)
+            if getattr(args, 'resize', None):
+                x = resize_bilinear_tf1(x, args.resize[1], args.resize[0])
+            if getattr(args, 'grayscale', False) and x.shape[-1] == 3:
+                x = (x * torch.tensor([0.2989, 0.5870, 0.1140], device=x.device)).sum(-1, keepdim=True)
+            return x.contiguous()
+        seed = args.seed if isinstance(getattr(args, 'seed', None), int) else 0
+        src = StreamingSource(imgs_u8, args.batch_size, sess.device, buffer_size=getattr(args, 'buffer_size', 10000), seed=seed,
+                              rank=sess.rank, world=sess.world_size, shuffle=getattr(args, 'shuffle', True), post=post)
+        probe = post(torch.zeros((1,) + tuple(imgs_u8.shape[1:]), device=sess.device))
+        return src, n, tuple(probe.shape[1:])
     x = torch.from_numpy(np.ascontiguousarray(imgs_u8)).to(sess.device).float() / 255.0
     if pad_to_32 and x.shape[1] == 28:                    # MNIST: 28 -> 32 so the 2x deconv ladder fits (SURVEY App. C-1)
         x = F.pad(x.permute(0, 3, 1, 2), (2, 2, 2, 2)).permute(0, 2, 3, 1)

@@ -364,6 +364,20 @@ int tdg_png_unfilter(const unsigned char* filtered, int rows, int row_bytes, int
 int tdg_jpeg_info(const unsigned char* data, size_t nbytes, int* width, int* height, int* components);
 int tdg_jpeg_decode(const unsigned char* data, size_t nbytes, unsigned char* rgb, size_t rgb_bytes);
 
+/* ---- tdg_shuffle_draw / tdg_gather_rows: the host side of the streaming input pipeline (no device work) --------------
+ *      `d.repeat().shuffle(buffer_size)` of the reference (data.py:56-57, train.py:171-174: buffer_size 10000) on example
+ *      INDICES: `buf[0 .. buf_len)` holds the indices currently in the shuffle buffer, `*next_in` the next index of the
+ *      repeated stream 0, 1, ..., n_total-1, 0, 1, ... to enter it.  Each of the `count` draws picks a uniformly random slot
+ *      (xoshiro256** on state[4], Lemire's unbiased range reduction), writes its index to `out` and refills the slot from
+ *      the stream -- tf.data's ShuffleDataset semantics: an example can appear at most ~buf_len draws before its stream
+ *      position, never later than the buffer lets it wait.  The caller fills buf with the first min(buffer_size, ...)
+ *      stream indices and sets *next_in behind them.
+ *      tdg_gather_rows: out[i] = src[idx[i]] for rows of `row_bytes` bytes (the batch assembled in pinned host memory). */
+int tdg_shuffle_draw(int64_t* buf, int64_t buf_len, uint64_t* state, int64_t* next_in, int64_t n_total, int64_t count,
+                     int64_t* out);
+int tdg_gather_rows(const unsigned char* src, int64_t n_rows, size_t row_bytes, const int64_t* idx, int64_t count,
+                    unsigned char* out);
+
 #ifdef __cplusplus
 }
 #endif
