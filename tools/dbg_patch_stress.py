@@ -1,4 +1,5 @@
-"""Diagnostics: run-to-run determinism of igemm_fwd_patch_kernel (a race shows as a run that differs from the first)."""
+"""Diagnostics: run-to-run determinism of igemm_fwd_patch_kernel and igemm_wgrad_patch_kernel (a race shows as a run that differs
+from the first).  Round 4, 200 repetitions per form on the two headline shapes: profiles/r04_patch_stress.txt."""
 import importlib, os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,8 @@ def run(n, h, w, cin, cout, k, s, reps):
     conv = K.Conv(big, small, k, k, s, pt, pt)
     conv.pack((torch.randn(k, k, cin, cout, generator=g) * 0.05).to(dev))
     junk = torch.empty(64 << 20, dtype=torch.float32, device=dev)
-    for name in ('fwd', 'bwd_data'):
+    dw = torch.zeros(k, k, cin, cout, device=dev)
+    for name in ('fwd', 'bwd_data', 'bwd_filter'):
         ref = None
         nbad = 0
         for r in range(reps):
@@ -25,9 +27,11 @@ def run(n, h, w, cin, cout, k, s, reps):
                 junk.normal_()                    # disturb caches / timing between launches
             if name == 'fwd':
                 o = small.like(); conv.fwd(big.ptr(), o.ptr(), n); shape = (n, oh, ow, small.cs)
-            else:
+            elif name == 'bwd_data':
                 o = big.like(); conv.bwd_data(small.ptr(), o.ptr(), n); shape = (n, h, w, big.cs)
-            cur = o.buf.float()
+            else:
+                conv.bwd_filter(big.ptr(), small.ptr(), dw, n); shape = (k, k, cin, cout)
+            cur = (o.buf.float() if name != 'bwd_filter' else dw.reshape(-1).clone())
             if ref is None:
                 ref = cur.clone()
                 print(name, L.load().tdg_last_kernel().decode())
