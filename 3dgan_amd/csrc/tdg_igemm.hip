@@ -2490,6 +2490,7 @@ struct FusedBwdArgs {
   int TA, ntr;           // anchor rows per workgroup, row tiles per image
   int TW, ntc;           // anchor columns per workgroup, column tiles per row tile (wide images: the halo tile would not fit)
   int y_off;             // LDS byte offset of the halo tile
+  unsigned long long* stamps;   // diagnostic build (-DTDG_STAMPS) only: per-wave phase boundaries; null otherwise
   FastDiv fd_vpp, fd_hc;
   int act, mask_mode, accumulate;
   float leak;
@@ -2505,6 +2506,8 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
   const int img = tile / a.ntr, rt = tile - img * a.ntr;
   const int a0 = rt * a.TA, c0 = ct * a.TW;
   const int HR = a.TA + a.nhm - 1, HC = a.TW + a.nwm - 1;     // halo tile (pixels)
+  unsigned long long fs0 = 0, fs1 = 0, fs2 = 0, fs3 = 0, fs4 = 0;
+  TDG_STAMP(fs0);
 
   // ---- stage the merged filter (straight copy) and the halo tile by LDS-DMA: every 16-byte chunk of both images
   // is one lane of a wave instruction (destination lane-linear), halo pixels outside the image, the pitch padding
@@ -2532,7 +2535,9 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rY, (lds_ptr_t)(sYb + g0 * 16), 16, ok ? (unsigned)(((r * a.SW + c) * a.Cs + v * 8) * 2) : OOB_OFFSET, 0, 0, 0);
     }
   }
+  TDG_STAMP(fs1);
   __syncthreads();
+  TDG_STAMP(fs2);
 
   const int r16 = lane & 15, q = lane >> 4;
   const int npix = a.TA * a.TW, ntile = (npix + 15) / 16;
@@ -2564,6 +2569,10 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw, f1, acc1, 0, 0, 0);
         }
       }
+#ifdef TDG_STAMPS
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+    TDG_STAMP(fs3);
+#endif
     // ---- epilogue: lane holds columns 4q..4q+3 = (class, c) of its pixel ------------------------------------
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -2588,6 +2597,16 @@ __global__ void __launch_bounds__(512) bwd_fused_kernel(const FusedBwdArgs a) {
       }
     }
   }
+#ifdef TDG_STAMPS
+  if (a.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(fs4);
+    if (lane == 0) {
+      unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 8;
+      o[0] = fs0; o[1] = fs1; o[2] = fs2; o[3] = fs3; o[4] = fs4;
+    }
+  }
+#endif
 }
 
 // ============================================================================================
@@ -4158,6 +4177,9 @@ int tdg_conv2d_bwd_data(const TdgConvDesc* d, int n_images, const void* y, const
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set = true;
     }
+#ifdef TDG_STAMPS
+    f.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
     tdg_note_kernel("bwd_fused_kernel<bf16>");
     tdg_timing_start("bwd_fused_kernel<bf16>", conv_flops(d, n_images), (hipStream_t)stream);
     hipLaunchKernelGGL(bwd_fused_kernel, dim3(n_images * fp.ntr * fp.ntc), dim3(512), fp.lds, (hipStream_t)stream, f);

@@ -9,7 +9,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for path in glob.glob('gpurun_out/pmc_conv_$TAG/**/*counter_collection.csv', recursive=True):
     for row in csv.DictReader(open(path)):
         k = row['Kernel_Name'][:60]
-        if 'igemm' not in k: continue
+        if 'igemm' not in k and 'fused' not in k and 'thin' not in k: continue
         a = acc[k][row['Counter_Name']]; a[0] += 1; a[1] += float(row['Counter_Value'])
 for k, cs in acc.items():
     v = {c: t / n for c, (n, t) in cs.items()}
