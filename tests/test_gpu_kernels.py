@@ -205,6 +205,50 @@ def test_conv_patch_resident_kernel(case, monkeypatch):
     assert 'igemm_fwd_patch_kernel' in pkg('_lib').load().tdg_last_kernel().decode()
 
 
+def _wgrad_random_cases(n_cases=28, seed=20261005):
+    """Seeded random geometries inside the patch-resident filter gradient's plan (whole images per 64-row step, 8-channel
+    slices, 208-column tiles): output grids whose size divides 64, stride 1 / 2, 2x2 .. 5x5 filters, 1 - 13 slices, ragged
+    column tiles, image counts that leave ragged last steps and single-step splits."""
+    rng = np.random.default_rng(seed)
+    grids = [(1, 1), (2, 2), (4, 4), (8, 8), (2, 4), (4, 2), (8, 4), (4, 8), (2, 8), (1, 4), (16, 4), (4, 16)]
+    out = []
+    while len(out) < n_cases:
+        oh, ow = grids[rng.integers(len(grids))]
+        s = int(rng.integers(1, 3))
+        k = int(rng.integers(max(2, s), 6))
+        cin = int(rng.choice([8, 16, 24, 40, 64, 104]))
+        cout = int(rng.choice([168, 184, 200, 208, 328, 400, 416]))
+        n = int(rng.integers(1, 3 * max(1, 64 // (oh * ow)) + 3))
+        if k * k * cin < 128 or k * k > 32:
+            continue                                          # (below the LDS-DMA kernels' K threshold / the tap table)
+        out.append((n, oh * s, ow * s, cin, cout, k, s))
+    return out
+
+
+@pytest.mark.parametrize('case', _wgrad_random_cases())
+def test_wgrad_patch_random_geometries(case):
+    """Each case must (a) take igemm_wgrad_patch_kernel or, where its plan refuses, a slab kernel -- never fault -- and (b)
+    match the float64 oracle; two launches are bit-equal."""
+    K = pkg('kernels')
+    n, h, w, cin, cout, k, s = case
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(hash(case) % 100000)
+    x = bf16_round(rng.standard_normal((n, h, w, cin)).astype(np.float32))
+    big, small, conv = make_conv(K, 1, n, h, w, cin, cout, k, s, dev)
+    dy = bf16_round(rng.standard_normal((n, small.h, small.w, cout)).astype(np.float32))
+    big.set(x)
+    small.set(dy)
+    ref = T.conv2d_backprop_filter(x.astype(np.float64), (k, k, cin, cout), dy.astype(np.float64), s)
+    dw = [torch.zeros(k, k, cin, cout, device=dev) for _ in range(2)]
+    for d in dw:
+        conv.bwd_filter(big.ptr(), small.ptr(), d, n)
+    kern = pkg('_lib').load().tdg_last_kernel().decode()
+    assert relerr(dw[0].cpu().numpy(), ref) < TOL[1], (case, kern)
+    assert torch.equal(dw[0], dw[1]), (case, kern)
+    if 64 % (small.h * small.w) == 0 and cin % 8 == 0 and pkg('_lib') and 'igemm_wgrad_dma' in kern:
+        print('note: slab kernel on', case)
+
+
 BLOCK_PATCH_CASES = [
     # n, h, w, cin, cout, k, stride, forward dispatch expected
     (2, 64, 64, 64, 128, 4, 2, '256,128'),     # pix2pix e2 at quarter size: 32 x 32 outputs = four 16 x 16 blocks per image; bwd-data: 64 columns
