@@ -1585,6 +1585,257 @@ __global__ void __launch_bounds__(512, 2) igemm_fwd_patch_kernel(const IgArgs ar
 #endif
 }
 
+// ============================================================================================
+// Block-patch forward GEMM with EVERY wave loading and multiplying (igemm_fwd_bp_kernel<BN>, round 4).
+//
+// For the 4 x 4 / stride-2 layers of pix2pix (16 - 64 K steps, 128 / 64 columns).  Stamps of igemm_fwd_dma_kernel<256,128,3> on
+// those shapes (tools/stamp_conv.py): a K step takes ~1 980 clocks for 1 024 of MFMA (issue 200, multiply 1 030 - 1 440, barrier
+// 90 - 590, 160 unstamped), prologue ~8 000, epilogue ~7 000; the 4 + 4 specialised patch form has its four loader waves issue 30
+// pieces a step at ~130 clocks each -- no slack.  Here, as in igemm_wgrad_patch_kernel:
+//   * tile 256 rows = one 16 x 16-anchor block of one image, BN = 128 | 64 columns, eight waves as 4 (M) x 2 (N), 64 x BN/2 each;
+//   * K in 32-channel slices (CK = 4: one MFMA k-slice = the four chunks of one (slice, tap) UNIT, a 64-deep step = two units), the
+//     taps in groups of exactly four (the parity groups of a 4x4 stride-2 filter, the 2x2 taps of its backward-data classes): a phase
+//     (slice, group) is two steps and reads ONE patch: the block's lattice window with a halo of one pixel, 18 x 18 pixels of 80 bytes;
+//   * fragment address = per-lane constant (row's pixel, k-group) + the unit's offset (patch buffer, tap displacement) from an LDS
+//     table: one v_add per A fragment, no masks (a tap outside the image reads a halo pixel that was an out-of-range source);
+//   * 3-stage filter ring + 3 patch buffers; per step a wave issues NSLOT pieces -- the filter rows of step s+3 and half of the
+//     patch of phase (s+4)/2 -- behind the step's skewed barrier, and waits for its own pieces of step s+1 with a counted vmcnt.
+// The host selects it only for classes that meet these assumptions (plan_fwd_bp); everything else keeps its kernel.
+// ============================================================================================
+__device__ __forceinline__ void bp_dma(const i32x4& rsrc, unsigned voff, unsigned soff, unsigned lds_byte) {
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_byte) : "memory");
+}
+#define BP_PIECES 28
+// pieces of a group that ride on the tail tiles of the step in front of it (the rest: on the next step's slice-0 tiles)
+#define BP_NSLOT(BN) (((BN) / 8 + BP_PIECES / 2 + 7) / 8)
+#define BP_NTAIL(BN) ((BN) / 32 - ((BN) / 64 > 0 ? (BN) / 64 : 1))
+#define BP_NPB(BN) (BP_NSLOT(BN) / 2 < BP_NTAIL(BN) ? BP_NSLOT(BN) / 2 : BP_NTAIL(BN))
+template <int BN>
+__global__ void __launch_bounds__(512, 2) igemm_fwd_bp_kernel(const IgArgs args) {
+  using T = bf16_t;
+  constexpr int BM = 256, NTHR = 512, TM = 4, TN = BN / 32;
+  constexpr int STAGE = BN * IG_BKB, NS = 3, PATCHB = BP_PIECES * 1024;
+  constexpr int NBP = BN / 8;                              // filter pieces per step
+  constexpr int NPH = BP_PIECES / 2;                       // patch pieces per step (a phase = two steps)
+  constexpr int NSLOT = (NBP + NPH + 7) / 8;               // pieces per wave and step
+  constexpr int OFF_RING = PT_ZEROB, OFF_PATCH = OFF_RING + NS * STAGE, OFF_DUMMY = OFF_PATCH + PT_NPB * PATCHB, OFF_TAB = OFF_DUMMY + 1024;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const IgClass& cl = args.cls[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = bid / args.ntiles_n;
+  const int tile_n = bid - tile_m * args.ntiles_n;
+  const int M = cl.M, nsteps = cl.nsteps, ntaps = cl.ntaps, G = cl.ngroups, QW = cl.QW, QH = cl.QH, halo = cl.halo;
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)smem;
+  int* sU = reinterpret_cast<int*>(smem + OFF_TAB);       // per unit: patch buffer + tap displacement (LDS byte offset)
+  float* sBias = reinterpret_cast<float*>(smem + OFF_TAB + 2 * nsteps * 4);
+  if (tile_m * BM >= M) {
+    if (args.col_partial && tid < BN) {
+      const int n = args.n_begin + tile_n * BN + tid;
+      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * args.N;
+      if (n < args.N) { pr[n] = 0.f; pr[args.N + n] = 0.f; }
+    }
+    return;
+  }
+  const int m0 = tile_m * BM, n0 = args.n_begin + tile_n * BN;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int wm = wave & 3, wn = wave >> 2;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int sgs = args.sigma - 1;
+
+  unsigned long long bs0 = 0, bs1 = 0, bs2 = 0, bs3 = 0, bw_wait = 0, bw_bar = 0;
+  TDG_STAMP(bs0);
+  // ---- tables: zero pixel, unit offsets, bias row -----------------------------------------------------------------
+  if (tid < PT_ZEROB / 4) reinterpret_cast<int*>(smem)[tid] = 0;
+  for (int u = tid; u < 2 * nsteps; u += NTHR) {
+    const unsigned sl = fd_div((unsigned)u, cl.fd_nt);
+    const int t = u - (int)sl * ntaps;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) gi = (k < G && t >= cl.grp[k].t0) ? k : gi;
+    const int pk = cl.tap[t];
+    const int dhq = (tap_dh(pk) - cl.grp[gi].ph) >> sgs, dwq = (tap_dw(pk) - cl.grp[gi].pw) >> sgs;
+    const int ph = (int)sl * G + gi;
+    sU[u] = (int)lds0 + OFF_PATCH + (ph % PT_NPB) * PATCHB + (dhq * QW + dwq) * PT_PIXB;
+  }
+  if (tid < BN) sBias[tid] = (args.bias && n0 + tid < args.N) ? args.bias[n0 + tid] : 0.f;
+
+  // ---- loop-invariant fragment addresses ----------------------------------------------------------------------------
+  unsigned abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int loc = wm * 64 + i * 16 + r16;
+    const int a_ = (int)fd_div((unsigned)loc, cl.fd_gw), b_ = loc - a_ * cl.GW;            // (one block per tile: loc < GH * GW = 256)
+    abase[i] = (unsigned)(((a_ + halo) * QW + b_ + halo) * PT_PIXB + q * 16);
+  }
+  const int swl = (r16 >> 1) & 7;
+  const unsigned bb0 = lds0 + OFF_RING + (unsigned)((wn * TN * 16 + r16) * IG_BKB + (((0 * 4 + q) ^ swl) << 4));
+  const unsigned bb1 = lds0 + OFF_RING + (unsigned)((wn * TN * 16 + r16) * IG_BKB + (((1 * 4 + q) ^ swl) << 4));
+
+  // ---- the loader: slot k of wave w is piece w + 8 k of [NBP filter pieces | NPH patch pieces | dummies] ----------------
+  const i32x4 rB = make_rsrc_words(static_cast<const char*>(args.wpack) + cl.w_off_bytes, args.w_bytes - cl.w_off_bytes);
+  const i32x4 rA = make_rsrc_words(args.src, args.src_bytes);
+  const i32x4 rZ = i32x4{rB[0], rB[1], 0, rB[3]};           // zero records: every lane out of range (steps past the end)
+  unsigned vo[NSLOT], vo2[NSLOT];                          // per-lane source offsets (patch slots: first / second half of a patch)
+  {
+    const int nblk = cl.nbh * cl.nbw > 1 ? cl.nbh * cl.nbw : 1;
+    const int img = tile_m / nblk, br = tile_m - img * nblk, bi = br / (cl.nbw > 0 ? cl.nbw : 1), bj = br - bi * (cl.nbw > 0 ? cl.nbw : 1);
+    const int LH = args.SH >> sgs, LWd = args.SW >> sgs;
+    static_for<0, NSLOT>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      const int P = wave + 8 * k;
+      if (P < NBP) {
+        const int row = P * 8 + (lane >> 3), n = n0 + row;
+        const int lch = (lane & 7) ^ ((row >> 1) & 7);
+        vo[k] = vo2[k] = n < args.N ? ((unsigned)n * (unsigned)cl.Kp + (unsigned)(lch * 8)) * 2u : OOB_OFFSET;
+      } else {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int PP = hh * NPH + (P - NBP);
+          const int c = PP * 64 + lane;
+          const int pl = c / PT_CK, j = c - pl * PT_CK;
+          const int qh = (int)fd_div((unsigned)pl, cl.fd_qw), qw = pl - qh * QW;
+          const int lh = bi * cl.GH - halo + qh, lw = bj * cl.GW - halo + qw;
+          const bool ok = P - NBP < NPH && j < 4 && pl < QH * QW && (unsigned)lh < (unsigned)LH && (unsigned)lw < (unsigned)LWd;
+          const unsigned o = ok ? (unsigned)((((img * args.SH + args.sigma * lh) * args.SW + args.sigma * lw) * args.Cs + j * 8) * 2) : OOB_OFFSET;
+          if (hh == 0) vo[k] = o; else vo2[k] = o;
+        }
+      }
+    });
+  }
+  // group g (g >= 0): the filter rows of step g and the (g + 1) % 2 half of the patch of phase (g + 1) / 2  (phase 0 whole with group 0)
+  auto piece = [&](auto k_c, int g, int st) {
+    constexpr int k = decltype(k_c)::value;
+    const int P = wave + 8 * k;
+    if constexpr (8 * k + 7 < NBP) {                       // filter rows of step g into ring stage st
+      const bool live = g < nsteps;
+      bp_dma(live ? rB : rZ, vo[k], (unsigned)(g * IG_BKB), lds0 + (unsigned)(OFF_RING + st * STAGE + P * 1024));
+    } else {
+      const int php = (g + 1) >> 1, hh = (g + 1) & 1;      // phase and half
+      const int sl = php / G, gi = php - sl * G;
+      const bool real = P - NBP < NPH;                    // (a slot past the patch's pieces writes its zeros to a dummy KiB)
+      const bool live = real && php < args.nslices * G;  // (a phase past the last one: zeros into a buffer nobody reads any more)
+      const unsigned delta = live ? (unsigned)(((cl.grp[gi < G ? gi : 0].ph * args.SW + cl.grp[gi < G ? gi : 0].pw) * args.Cs + sl * 32) * 2) : 0u;
+      const int buf = php % PT_NPB;
+      const unsigned dst = lds0 + (unsigned)(real ? OFF_PATCH + buf * PATCHB + (hh * NPH + (P - NBP)) * 1024 : OFF_DUMMY);
+      bp_dma(live ? rA : rZ, hh ? vo2[k] : vo[k], delta, dst);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 FA[2][TM], FB[2][TN];
+  auto mma_tile = [&](auto ks_c, auto j_c) {
+    constexpr int ks = decltype(ks_c)::value, j = decltype(j_c)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[ks][j], FA[ks][i], acc[i][j], 0, 0, 0);
+  };
+  auto readA = [&](auto ks_c, auto i_c, int uo) {
+    constexpr int ks = decltype(ks_c)::value, i = decltype(i_c)::value;
+    FA[ks][i] = pt_lds_frag((int)(abase[i] + (unsigned)uo));
+  };
+  auto readB = [&](auto st_c, auto ks_c, auto j_c) {
+    constexpr int st = decltype(st_c)::value, ks = decltype(ks_c)::value, j = decltype(j_c)::value;
+    FB[ks][j] = pt_lds_frag((int)((ks ? bb1 : bb0) + (unsigned)(st * STAGE + j * 16 * IG_BKB)));
+  };
+
+  // ---- prologue: groups 0, 1, 2 (filter steps 0 - 2; patch phase 0 whole, phase 1 whole) -------------------------------------
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();                                          // tables and the zero pixel are in LDS before any LDS-DMA is pending
+  static_for<0, NSLOT>([&](auto k_c) { piece(k_c, 0, 0); });                 // filter 0 + patch 0 second half ...
+  {                                                        // ... and patch 0 FIRST half: group "-1" carries it
+    static_for<0, NSLOT>([&](auto k_c) {
+      constexpr int k = decltype(k_c)::value;
+      if constexpr (8 * k + 7 >= NBP) piece(k_c, -1, 0);
+    });
+  }
+  static_for<0, NSLOT>([&](auto k_c) { piece(k_c, 1, 1); });
+  static_for<0, BP_NPB(BN)>([&](auto k_c) { piece(k_c, 2, 2); });              // (the rest of group 2 rides on step 0's slice-0 tiles)
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT + BP_NPB(BN)) : "memory");   // group 0 and patch 0 have landed; groups 1, 2 stay in flight
+  __syncthreads();
+  TDG_STAMP(bs1);
+  int uo0 = sU[0], uo1 = sU[1];                             // unit offsets of the step being multiplied
+  static_for<0, TM>([&](auto i_c) { readA(IntC<0>{}, i_c, uo0); });
+  static_for<0, TN>([&](auto j_c) { readB(IntC<0>{}, IntC<0>{}, j_c); });
+
+  constexpr int TS = TN / 2 > 0 ? TN / 2 : 1, NTAIL = TN - TS;
+  constexpr int NPB = NSLOT / 2 < NTAIL ? NSLOT / 2 : NTAIL, NPA = NSLOT - NPB, PPT = (NPA + TN - 1) / TN;
+  static_assert(NPB == BP_NPB(BN) && NSLOT == BP_NSLOT(BN), "prologue and loop agree on the piece schedule");
+  int s = 0;
+  auto body = [&](auto st_c) {
+    constexpr int ST = decltype(st_c)::value, ST1 = (ST + 1) % NS, ST2 = (ST + 2) % NS;
+    const int un = 2 * (s + 1) < 2 * nsteps ? 2 * (s + 1) : 0;                // next step's units (clamped: the last fragments are never used)
+    const int nu0 = sU[un], nu1 = sU[un + 1];
+    // ---- part A: slice 0 (+ the reads of slice 1, + the remaining pieces of group s + 2), then slice-1 tiles [0, TS)
+    static_for<0, TN>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
+      constexpr int a_lo = (j * TM) / TN, a_hi = ((j + 1) * TM) / TN;
+      readB(st_c, IntC<1>{}, j_c);
+      static_for<a_lo, a_hi>([&](auto i_c) { readA(IntC<1>{}, i_c, uo1); });
+      mma_tile(IntC<0>{}, j_c);
+      constexpr int p_lo = NPB + j * PPT < NSLOT ? NPB + j * PPT : NSLOT;
+      constexpr int p_hi = NPB + (j + 1) * PPT < NSLOT ? NPB + (j + 1) * PPT : NSLOT;
+      static_for<p_lo, p_hi>([&](auto k_c) { piece(k_c, s + 2, ST2); });
+    });
+    static_for<0, TS>([&](auto j_c) { mma_tile(IntC<1>{}, j_c); });
+    // ---- the step's barrier: this wave's pieces of group s + 1 have landed; every read of stage ST has been issued and waited for
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef TDG_STAMPS
+    unsigned long long wt1, wt2, wt3;
+    TDG_STAMP(wt1);
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");
+#ifdef TDG_STAMPS
+    TDG_STAMP(wt2);
+#endif
+    __syncthreads();
+#ifdef TDG_STAMPS
+    TDG_STAMP(wt3);
+    bw_wait += wt2 - wt1; bw_bar += wt3 - wt2;
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- part B: the rest of slice 1; underneath, the slice-0 fragments of step s + 1 and the first pieces of group s + 3
+    static_for<0, NTAIL>([&](auto u_c) {
+      constexpr int u = decltype(u_c)::value, j = TS + u;
+      constexpr int b_lo = (u * TN) / NTAIL, b_hi = ((u + 1) * TN) / NTAIL;
+      if constexpr (u == 0) static_for<0, TM>([&](auto i_c) { readA(IntC<0>{}, i_c, nu0); });
+      static_for<b_lo, b_hi>([&](auto jj_c) { readB(IntC<ST1>{}, IntC<0>{}, jj_c); });
+      mma_tile(IntC<1>{}, IntC<j>{});
+      if constexpr (u < NPB) piece(u_c, s + 3, ST);
+    });
+    uo0 = nu0; uo1 = nu1;
+    ++s;
+  };
+  const int nsteps3 = (nsteps + NS - 1) / NS * NS;          // (whole ring cycles: up to two extra steps on zero-fill pieces)
+  while (s < nsteps3) {
+    body(IntC<0>{});
+    body(IntC<1>{});
+    body(IntC<2>{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                          // every wave has read its last fragments, every piece has landed: the epilogue stages over the ring
+  TDG_STAMP(bs2);
+
+  static_assert(BM * (BN * 2 + 16) + BM * 8 + 2 * (NTHR / BN) * BN * 4 <= OFF_TAB, "epilogue staging must not reach the tables");
+  staged_epilogue_bf16<BM, BN, TM, TN, NTHR>(acc, smem, sBias, true, wm * 64, wn * TN, TN, tid, r16, q, m0, n0, M, tile_m, args, cl);
+#ifdef TDG_STAMPS
+  if (args.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TDG_STAMP(bs3);
+    if (lane == 0) {
+      unsigned long long* o = args.stamps + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o[0] = bs0; o[1] = bs1; o[2] = bs2; o[3] = bs3;
+      unsigned long long* o2 = args.stamps + 262144 + ((size_t)(blockIdx.z * gridDim.x + blockIdx.x) * 8 + wave) * 4;
+      o2[0] = bw_wait; o2[1] = bw_bar;
+    }
+  }
+#endif
+}
+
 // Second half of a split-K forward-type GEMM: out[pixel(m)][n] = epilogue(sum over splits of slab[split][class][m][n]).
 // One thread per (class, row, 4 columns); splits are added in ascending order (deterministic).
 template <typename T>
@@ -3129,7 +3380,7 @@ int launch_fwd_dma(IgArgs& a, int mmax, hipStream_t s, int n_begin = 0, int ntil
 // fd_ghw, fd_gw are rewritten to the block's and nbh, nbw, halo set -- only when the whole plan holds), a source whose
 // sub-lattices all have the same shape, patches that fit PIECES KiB, tap groups in K order, and a phase schedule in which
 // every patch lands two steps before its first read (the loader's own rule, simulated here).
-template <int BM, int BN = 208, int CK = PT_CK, int PIECES = PT_PIECES>
+template <int BM, int BN = 208, int CK = PT_CK, int PIECES = PT_PIECES, bool FORCE_HALO = false>
 bool plan_fwd_patch(IgArgs& a, int mmax) {
   const int enabled = getenv("TDG_PATCH") ? atoi(getenv("TDG_PATCH")) : 1;     // diagnostics: 0 = igemm_fwd_dma_kernel, 2 = also on small grids
   if (!enabled || (int)a.fd_ck.d != CK || a.accumulate || (a.N & 3) || (a.Cso & 3)) return false;
@@ -3161,7 +3412,7 @@ bool plan_fwd_patch(IgArgs& a, int mmax) {
     }
     c.ngroups = ng;
     Geo& g = geo[ci];
-    if (BM % ghw == 0) {                                       // whole images: the patch is the image's sub-lattice, taps outside it are masked
+    if (BM % ghw == 0 && !(FORCE_HALO && ghw == BM)) {         // whole images: the patch is the image's sub-lattice, taps outside it are masked
       g = Geo{c.GH, c.GW, 1, 1, 0, LH, LWd};
     } else {                                                   // a block of one image with a halo of dmax lattice pixels
       int bw = c.GW < 16 ? c.GW : 16;
@@ -3270,6 +3521,70 @@ int launch_fwd_patch(IgArgs& a, int mmax, hipStream_t s) {
   return TDG_OK;
 }
 
+// igemm_fwd_bp_kernel: the block-patch plan (on a copy: the classes are rewritten only when everything holds) plus what the
+// all-wave kernel assumes on top: one 16 x 16 block per row tile with a halo'd patch, tap groups of exactly four, a K of whole
+// two-step phases.
+template <int BN>
+bool plan_fwd_bp(IgArgs& a, int mmax) {
+  const char* e = getenv("TDG_BP");                         // variant tests: 0 = the 4 + 4 wave-specialised patch kernel
+  if (e && atoi(e) == 0) return false;
+  IgArgs t = a;
+  if (!plan_fwd_patch<256, BN, 4, BP_PIECES, true>(t, mmax)) return false;
+  for (int ci = 0; ci < t.nclasses; ++ci) {
+    const IgClass& c = t.cls[ci];
+    if (c.GH * c.GW != 256 || c.halo < 1 || c.QH * c.QW * PT_PIXB > BP_PIECES * 1024) return false;
+    if (c.ntaps % 4 || c.ntaps != 4 * c.ngroups) return false;
+    for (int g = 0; g < c.ngroups; ++g)
+      if (c.grp[g].nt != 4) return false;
+    if (c.nsteps != 2 * t.nslices * c.ngroups || c.M % 256) return false;
+  }
+  a = t;
+  return true;
+}
+
+template <int BN>
+int launch_fwd_bp(IgArgs& a, int mmax, hipStream_t s) {
+  a.n_begin = 0;
+  a.ntiles_n = tdg_ceil_div(a.N, BN);
+  a.ntiles_m_max = tdg_ceil_div(mmax, 256);
+  if (t_col) {
+    const int nblk = a.nclasses * a.ntiles_m_max;
+    if ((size_t)nblk * 2 * a.N * sizeof(float) <= t_col->col_partial_bytes) {
+      a.col_partial = t_col->col_partial;
+      a.col_mode = t_col->col_mode;
+      a.col_images = t_col->col_images;
+      *t_col->col_nblk_out = nblk;
+    }
+  }
+  a.ksplit = 1;
+  a.steps_per_split = 1 << 30;
+  a.slab = nullptr;
+  int smax = 0;
+  for (int c = 0; c < a.nclasses; ++c) smax = a.cls[c].nsteps > smax ? a.cls[c].nsteps : smax;
+  const size_t lds = PT_ZEROB + 3 * (size_t)BN * IG_BKB + PT_NPB * (size_t)BP_PIECES * 1024 + 1024 + (size_t)smax * 8 + BN * sizeof(float);
+  if (lds > 160 * 1024) {
+    tdg_set_error("igemm_fwd_bp: %zu bytes of LDS", lds);
+    return TDG_EUNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_fwd_bp_kernel<BN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+#ifdef TDG_STAMPS
+  a.stamps = getenv("TDG_STAMP_PTR") ? (unsigned long long*)strtoull(getenv("TDG_STAMP_PTR"), nullptr, 0) : nullptr;
+#endif
+  static char name[64] = "";
+  if (!name[0]) snprintf(name, sizeof(name), "igemm_fwd_bp_kernel<bf16,256,%d>", BN);
+  tdg_note_kernel(name);
+  dim3 grid(a.ntiles_n * a.ntiles_m_max, 1, a.nclasses), block(512);
+  tdg_timing_start(name, t_flops, s);
+  hipLaunchKernelGGL((igemm_fwd_bp_kernel<BN>), grid, block, lds, s, a);
+  tdg_timing_stop(s);
+  TDG_HIP_LAUNCH_CHECK("igemm_fwd_bp");
+  return TDG_OK;
+}
+
 template <typename T>
 int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   constexpr int BM = 128;
@@ -3362,6 +3677,8 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
   // slices, 28 KiB patches>): 16 + 13 KB (128 columns) / 8 + 13 KB (64) of intake per K step instead of 16 + 32 / 8 + 16
   if constexpr (sizeof(T) == 2) {
     if (veca && dma_mode == 1 && (bn == 128 || bn == 64) && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW")) {
+      if (bn == 128 && a.N > 112 && plan_fwd_bp<128>(a, mmax)) return launch_fwd_bp<128>(a, mmax, s);
+      if (bn == 64 && a.N > 32 && plan_fwd_bp<64>(a, mmax)) return launch_fwd_bp<64>(a, mmax, s);
       if (bn == 128 && a.N > 112 && plan_fwd_patch<256, 128, 4, 28>(a, mmax)) return launch_fwd_patch<256, 128, 4, 28>(a, mmax, s);
       if (bn == 64 && a.N > 32 && plan_fwd_patch<256, 64, 4, 28>(a, mmax)) return launch_fwd_patch<256, 64, 4, 28>(a, mmax, s);
     }

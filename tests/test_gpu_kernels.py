@@ -251,20 +251,22 @@ def test_wgrad_patch_random_geometries(case):
 
 BLOCK_PATCH_CASES = [
     # n, h, w, cin, cout, k, stride, forward dispatch expected
-    (2, 64, 64, 64, 128, 4, 2, '256,128'),     # pix2pix e2 at quarter size: 32 x 32 outputs = four 16 x 16 blocks per image; bwd-data: 64 columns
-    (3, 32, 32, 128, 256, 4, 2, '256,128'),    # e3: one block per image, two column tiles
-    (5, 16, 16, 256, 512, 4, 2, '256,128'),    # e4 at 8 x 8 outputs: WHOLE-image tiles (four images), ragged last tile; bwd-data: blocks
-    (2, 64, 64, 64, 128, 5, 2, '256,128'),     # VAE c2 geometry (5 x 5, stride 2): tap groups of 9 / 6 / 6 / 4, halo 1
-    (2, 32, 32, 64, 128, 3, 1, '256,128'),     # stride 1: one tap group, blocks with a halo on every side
-    (2, 128, 128, 64, 64, 4, 2, '256,64'),     # 64-column tiles both ways (d7-like widths)
+    (2, 64, 64, 64, 128, 4, 2, 'igemm_fwd_bp_kernel<bf16,256,128>'),      # pix2pix e2 at quarter size: 32 x 32 outputs = four 16 x 16 blocks per image; bwd-data: 64 columns
+    (3, 32, 32, 128, 256, 4, 2, 'igemm_fwd_bp_kernel<bf16,256,128>'),     # e3: one block per image (halo'd whole-image patch), two column tiles
+    (5, 16, 16, 256, 512, 4, 2, 'igemm_fwd_patch_kernel<bf16,256,128>'),  # e4 at 8 x 8 outputs: WHOLE-image tiles (four images), ragged last tile; bwd-data: blocks
+    (2, 64, 64, 64, 128, 5, 2, 'igemm_fwd_patch_kernel<bf16,256,128>'),   # VAE c2 geometry (5 x 5, stride 2): tap groups of 9 / 6 / 6 / 4, halo 1
+    (2, 32, 32, 64, 128, 3, 1, 'igemm_fwd_patch_kernel<bf16,256,128>'),   # stride 1: one tap group of nine, blocks with a halo on every side
+    (2, 128, 128, 64, 64, 4, 2, 'igemm_fwd_bp_kernel<bf16,256,64>'),      # 64-column tiles both ways (d7-like widths)
+    (1, 256, 256, 64, 128, 4, 2, 'igemm_fwd_bp_kernel<bf16,256,128>'),    # e2 at full size: 64 blocks per image, every border block
     (2, 48, 32, 64, 128, 4, 2, None),          # 24 x 16 outputs: no 16 x 16 blocks -> the slab kernel (plan refused)
 ]
 
 
 @pytest.mark.parametrize('case', BLOCK_PATCH_CASES)
 def test_conv_block_patch_kernel(case, monkeypatch):
-    """igemm_fwd_patch_kernel<256, 128 | 64> (32-channel K slices, 28 KiB patches): row tiles of one 16 x 16 block of an image
-    with a halo'd patch, or of four whole images, forced onto small problems; forward, backward-data and filter gradient
+    """igemm_fwd_bp_kernel<128 | 64> (every wave loads and multiplies; 4x4 / stride-2 filters and their backward-data classes on
+    16 x 16-anchor blocks) and igemm_fwd_patch_kernel<256, 128 | 64> (32-channel K slices, 28 KiB patches: the other geometries): row
+    tiles of one 16 x 16 block of an image with a halo'd patch, or of four whole images, forced onto small problems; forward, backward-data and filter gradient
     against the oracle (the filter gradient runs on the 4-chunk K order of the packed operand), dispatch asserted, a second
     launch bit-equal."""
     K = pkg('kernels')
@@ -283,9 +285,9 @@ def test_conv_block_patch_kernel(case, monkeypatch):
     conv.fwd(big.ptr(), small.ptr(), n)
     kern = pkg('_lib').load().tdg_last_kernel().decode()
     if want is None:
-        assert 'igemm_fwd_patch_kernel' not in kern, kern
+        assert 'igemm_fwd_patch_kernel' not in kern and 'igemm_fwd_bp_kernel' not in kern, kern
     else:
-        assert 'igemm_fwd_patch_kernel<bf16,%s>' % want in kern, kern
+        assert want in kern, kern
     first = small.get().copy()
     small.set(np.zeros_like(first))
     conv.fwd(big.ptr(), small.ptr(), n)
