@@ -4,6 +4,8 @@
 // cross-lane sums use 64-wide wavefront shuffles.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "tdg_common.h"
 #include <type_traits>
 
@@ -129,14 +131,26 @@ __device__ unsigned g_ticket[1216];
 // the same rule covers).  Entry points concerned: tdg_sumsq, tdg_adam_step_dev, tdg_random_normal_dev,
 // tdg_random_uniform_f32_dev (include/tdg.h says so at each).
 static int ticket_stream_check(const char* who, void* stream) {
-  static hipStream_t first = nullptr;
-  static bool have = false;
+  // the slots (g_ticket) are per DEVICE; the remembered stream is kept per device ordinal and claimed with one atomic
+  // compare-exchange, so two host threads cannot both believe they were first
+  static std::atomic<void*> first[16];
+  static std::atomic<bool> have[16];
   hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing((hipStream_t)stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return TDG_OK;
-  if (!have) { first = (hipStream_t)stream; have = true; return TDG_OK; }
-  if (first != (hipStream_t)stream) {
-    tdg_set_error("%s: launched on stream %p, but kernels that take last-block tickets first ran on stream %p -- their "
-                  "device-global ticket slots allow ONE stream per process", who, stream, (void*)first);
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) {
+    (void)hipGetLastError();                              // (do not leave a sticky error for the next launch check to report)
+    st = hipStreamCaptureStatusNone;
+  }
+  if (st != hipStreamCaptureStatusNone) return TDG_OK;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  bool expected = false;
+  if (have[dev].compare_exchange_strong(expected, true)) { first[dev].store(stream); return TDG_OK; }
+  void* f = first[dev].load();
+  for (int spin = 0; f == nullptr && stream != nullptr && spin < 1000; ++spin) f = first[dev].load();   // (the claiming thread is between its two stores)
+  if (f != stream) {
+    tdg_set_error("%s: launched on stream %p, but kernels that take last-block tickets first ran on stream %p of device %d -- their "
+                  "device-global ticket slots allow ONE stream per device (a graph that holds such launches must be launched on that "
+                  "stream too)", who, stream, f, dev);
     return TDG_EINVAL;
   }
   return TDG_OK;

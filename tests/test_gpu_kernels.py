@@ -560,6 +560,25 @@ def test_optimizer_branches_match_oracle(name):
                                         'momentum': {'acc'}}[name]
 
 
+def test_ticketed_kernels_keep_to_one_stream():
+    """Kernels that hand their last block a ticket from a device-global slot (the *_dev RNG draws, Adam, sumsq) must not overlap
+    on the device: the library remembers, per device, the first stream that launched one and refuses any other with TDG_EINVAL."""
+    _lib, K = pkg('_lib'), pkg('kernels')
+    dev = torch.device('cuda:0')
+    out = torch.zeros(1024, device=dev)
+    draws = torch.zeros(1, dtype=torch.int32, device=dev)
+    cur = torch.cuda.current_stream(dev).cuda_stream
+    _lib.call('tdg_random_uniform_f32_dev', 1, 2, K.ptr(draws), 1024, K.ptr(out), cur)
+    torch.cuda.synchronize()
+    assert int(draws.item()) == 1 and float(out.min()) >= 0.0 and float(out.max()) < 1.0
+    other = torch.cuda.Stream(device=dev)
+    with pytest.raises(_lib.TdgError, match='ONE stream per device'):
+        _lib.call('tdg_random_uniform_f32_dev', 1, 2, K.ptr(draws), 1024, K.ptr(out), other.cuda_stream)
+    _lib.call('tdg_random_uniform_f32_dev', 1, 2, K.ptr(draws), 1024, K.ptr(out), cur)          # the first stream still works
+    torch.cuda.synchronize()
+    assert int(draws.item()) == 2
+
+
 def test_rng_statistics():
     K = pkg('kernels')
     L = pkg('_lib')
