@@ -119,3 +119,63 @@ def test_valid_padding_conv_family_matches_torch(case):
     dw = T.conv2d_backprop_filter(x, Wt.shape, dy, s, 'VALID')
     assert np.allclose(dx, tx.grad.permute(0, 2, 3, 1).numpy(), atol=1e-10)
     assert np.allclose(dw, tw.grad.permute(2, 3, 1, 0).numpy(), atol=1e-10)
+
+
+def test_forced_derivative_masks_hook_of_the_torch_oracle():
+    """oracle/torch_ref.py MASKS (the hook behind the headline-size parity test): with the oracle's OWN masks forced, losses and
+    gradients are unchanged to the last bit of float64; with ONE mask entry flipped the loss VALUES are still unchanged (the
+    activation's value is untouched) and the gradients move -- i.e. the hook changes derivatives and nothing else."""
+    import torch
+    from oracle import gan_ref as G
+    from oracle import torch_ref as TR
+    cfg = G.make_cfg('iwgan', (32, 32, 3), 8, 4)
+    P = TR.to_torch(G.init_params(cfg, 3, np.float64), torch.float64)
+    rng = np.random.default_rng(2)
+    x = torch.tensor(rng.uniform(-1, 1, (4, 3072)))
+    z = torch.tensor(rng.standard_normal((4, 8)))
+    al = torch.tensor(rng.uniform(0, 1, (4, 1)))
+
+    def run():
+        gl, dl = TR.losses(P, x, z, al, cfg)
+        gg = TR.grads_of(gl, P, 'generator/')
+        dg = TR.grads_of(dl, P, 'discriminator/')
+        return float(gl.detach()), float(dl.detach()), {k: v.detach().numpy().copy() for k, v in list(gg.items()) + list(dg.items())}
+    assert TR.MASKS is None
+    gl0, dl0, g0 = run()
+    # the oracle's own masks, recomputed layer by layer
+    masks = {}
+    with torch.no_grad():
+        g_ = 'generator/vars/'
+        h = z @ P[g_ + 'fc1/weights'] + P[g_ + 'fc1/bias']
+        pre = TR.batch_norm(h, P[G.g_bn_name(0)])
+        masks[('g', 0)] = (pre > 0).numpy()
+        h = torch.relu(pre).reshape(-1, cfg.s0h, cfg.s0w, 4 * cfg.L)
+        for i, name in enumerate(['dc1', 'dc2', 'dc3'], start=1):
+            pre = TR.batch_norm(TR.conv2d_transpose_same(h, P[g_ + name + '/weights']) + P[g_ + name + '/bias'], P[G.g_bn_name(i)])
+            masks[('g', i)] = (pre > 0).numpy()
+            h = torch.relu(pre)
+        img = torch.tanh(TR.conv2d_transpose_same(h, P[g_ + 'dc4/weights']) + P[g_ + 'dc4/bias']).reshape(4, -1)
+        d_ = 'discriminator/vars/'
+        for tag, inp in (('real', x), ('fake', img), ('hat', x + al * (img - x))):
+            h = inp.reshape(-1, cfg.H, cfg.W, cfg.C)
+            for i, name in enumerate(['c1', 'c2', 'c3']):
+                pre = TR.conv2d_same(h, P[d_ + name + '/weights'], 2) + P[d_ + name + '/bias']
+                masks[(tag, i)] = (pre > 0).numpy()
+                h = TR.lrelu(pre)
+    TR.MASKS = masks
+    try:
+        gl1, dl1, g1 = run()
+        assert (gl1, dl1) == (gl0, dl0)
+        for k in g0:
+            assert np.abs(g1[k] - g0[k]).max() <= 1e-12 * max(1.0, np.abs(g0[k]).max()), k
+        flipped = {k: v.copy() for k, v in masks.items()}
+        flipped[('hat', 1)].reshape(-1)[5] ^= True
+        TR.MASKS = flipped
+        gl2, dl2, g2 = run()
+        assert gl2 == gl0                                          # the generator loss does not see the x_hat path
+        assert abs(dl2 - dl0) <= 1e-9 * max(1.0, abs(dl0)) or dl2 != dl0      # (the penalty's VALUE depends on v = a derivative: it may move)
+        k = 'discriminator/vars/c2/weights'
+        assert np.abs(g2[k] - g0[k]).max() > 0                     # the critic's gradient moved: the hook reaches the double backward
+        assert all(np.array_equal(g2[n], g0[n]) for n in g0 if n.startswith('generator/'))
+    finally:
+        TR.MASKS = None
