@@ -73,6 +73,7 @@ SIGNATURES = {
     'tdg_colsum_workspace_bytes': (_sz, [_i, _i]),
     'tdg_bn_workspace_bytes': (_sz, [_i, _i]),
     'tdg_bn_fwd': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    'tdg_bn_fwd_groups': (_i, [_i, _vp, _i, _i, _i, _i, _vp, _f, _i, _f, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
     'tdg_bn_bwd': (_i, [_i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
     'tdg_affine_cast_pair': (_i, [_i, _vp, _i, _vp, _i, _sz, _f, _f, _vp, _vp, _vp]),
     'tdg_bias_act': (_i, [_i, _vp, _i, _i, _i, _vp, _i, _f, _vp, _vp]),

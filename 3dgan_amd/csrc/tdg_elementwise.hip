@@ -269,8 +269,10 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int r0 = blockIdx.x * g.rows_per_blk;
   const int r1 = min(g.rows, r0 + g.rows_per_blk);
-  const T* x = static_cast<const T*>(a.x);
+  // blockIdx.z = group (tdg_bn_fwd_groups: ngroups tensors of g.rows rows behind each other, one set of partial planes each)
+  const T* x = static_cast<const T*>(a.x) + (size_t)blockIdx.z * g.rows * g.xcs;
   const T* y = static_cast<const T*>(a.y);
+  float* const partial = a.partial + (size_t)blockIdx.z * gridDim.x * 2 * g.C;
   const int c = (blockIdx.y * CL + tx) * VW;
   Acc s0[VW], s1[VW];
 #pragma unroll
@@ -330,8 +332,8 @@ __global__ void __launch_bounds__(256) col_partial_kernel(const ColGeom g, const
     for (int e = 0; e < VW; ++e) {
       Acc t0 = 0, t1 = 0;
       for (int k = 0; k < RL; ++k) { t0 += sh[0][e][k * CL + tx]; t1 += sh[1][e][k * CL + tx]; }
-      a.partial[((size_t)blockIdx.x * 2 + 0) * g.C + c + e] = (float)t0;
-      a.partial[((size_t)blockIdx.x * 2 + 1) * g.C + c + e] = (float)t1;
+      partial[((size_t)blockIdx.x * 2 + 0) * g.C + c + e] = (float)t0;
+      partial[((size_t)blockIdx.x * 2 + 1) * g.C + c + e] = (float)t1;
     }
   }
 }
@@ -346,6 +348,8 @@ struct FinArgs {
   float* out0;          // stats (mean | rstd)   / dbeta / dw
   float* out1;          // bwd: mean sums [2][C] for the apply pass
   float beta_acc;
+  long long x0_group;   // FIN_BN_STATS with blockIdx.y = group: elements between the groups' first rows (their partial planes
+                        // and [2][C] statistics lie behind each other)
 };
 // CH channels x 256 / CH partial lanes per block: 8 x 32 for up to ~1k row blocks (C / 8 workgroups, short per-thread chains); 2 x 128
 // for the thousands of row tiles a GEMM epilogue reports on pix2pix's 128 x 128 / 256 x 256 layers (the 8 x 32 form: 9 - 20 us on
@@ -358,6 +362,7 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   __shared__ Acc sh[2][RL][CH];
   const int tx = threadIdx.x & (CH - 1), ty = threadIdx.x / CH;
   const int c = blockIdx.x * CH + tx;
+  const float* const partial = a.partial + (size_t)blockIdx.y * a.nblk * 2 * a.C;
   Acc s0 = 0, s1 = 0;
   if (c < a.C)
     for (int b0 = ty; b0 < a.nblk; b0 += 4 * RL) {
@@ -366,8 +371,8 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
       for (int u = 0; u < 4; ++u) {
         const int b = b0 + RL * u;
         const bool ok = b < a.nblk;
-        p0[u] = ok ? a.partial[((size_t)b * 2 + 0) * a.C + c] : 0.f;
-        p1[u] = (ok && MODE != FIN_ACC) ? a.partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
+        p0[u] = ok ? partial[((size_t)b * 2 + 0) * a.C + c] : 0.f;
+        p1[u] = (ok && MODE != FIN_ACC) ? partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) { s0 += p0[u]; s1 += p1[u]; }
@@ -381,11 +386,12 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   for (int k = 0; k < RL; ++k) { s0 += sh[0][k][tx]; s1 += sh[1][k][tx]; }
   const Acc inv = (Acc)1 / (Acc)a.rows;
   if (MODE == FIN_BN_STATS) {
-    const float pivot = a.pivot_f ? a.pivot_f[c] : (a.x0 ? to_f32<T>(static_cast<const T*>(a.x0)[c]) : 0.f);
+    const float pivot = a.pivot_f ? a.pivot_f[c] : (a.x0 ? to_f32<T>(static_cast<const T*>(a.x0)[(size_t)blockIdx.y * a.x0_group + c]) : 0.f);
     const Acc md = s0 * inv;
     const Acc var = s1 * inv - md * md > 0 ? s1 * inv - md * md : 0;
-    a.out0[c] = (float)(pivot + md);
-    a.out0[a.C + c] = (float)(1.0 / sqrt((double)var + (double)a.eps));
+    float* const out = a.out0 + (size_t)blockIdx.y * 2 * a.C;
+    out[c] = (float)(pivot + md);
+    out[a.C + c] = (float)(1.0 / sqrt((double)var + (double)a.eps));
   } else if (MODE == FIN_BN_BWD) {
     a.out0[c] = (float)((a.beta_acc != 0.f ? (Acc)a.beta_acc * a.out0[c] : 0) + s0);
     a.out1[c] = (float)(s0 * inv);
@@ -398,11 +404,11 @@ __global__ void __launch_bounds__(256) col_finalize_kernel(const FinArgs a) {
   }
 }
 template <typename T, int MODE>
-static void launch_col_finalize(const FinArgs& f, hipStream_t s) {
+static void launch_col_finalize(const FinArgs& f, hipStream_t s, int ngroups = 1) {
   if (f.nblk >= 1024)
-    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, 2>), dim3((f.C + 1) / 2), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, 2>), dim3((f.C + 1) / 2, ngroups), dim3(256), 0, s, f);
   else
-    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, FIN_CH>), dim3((f.C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, f);
+    hipLaunchKernelGGL((col_finalize_kernel<T, MODE, FIN_CH>), dim3((f.C + FIN_CH - 1) / FIN_CH, ngroups), dim3(256), 0, s, f);
 }
 
 template <typename T, int VW>
@@ -425,6 +431,11 @@ __global__ void __launch_bounds__(256) bn_fwd_apply_kernel(const ColGeom g, cons
   const int tx = threadIdx.x % CL, ty = threadIdx.x / CL;
   const int c = (blockIdx.y * CL + tx) * VW;
   if (c >= C) return;
+  // blockIdx.z = group (tdg_bn_fwd_groups): g.rows rows and one [2][C] set of statistics per group
+  stats += (size_t)blockIdx.z * 2 * C;
+  u += (size_t)blockIdx.z * g.rows * g.cs;
+  if (pre) pre += (size_t)blockIdx.z * g.rows * g.cs;
+  h += (size_t)blockIdx.z * g.rows * hcs;
   float mean[VW], rstd[VW], b[VW];
 #pragma unroll
   for (int e = 0; e < VW; ++e) { mean[e] = stats[c + e]; rstd[e] = stats[C + c + e]; b[e] = beta[c + e]; }
@@ -501,11 +512,11 @@ extern "C" size_t tdg_bn_workspace_bytes(int rows, int c) {
 extern "C" size_t tdg_colsum_workspace_bytes(int rows, int cols) { return tdg_bn_workspace_bytes(rows, cols); }
 
 template <typename T, int MODE>
-static int run_col_partial(const ColGeom& g, const ColArgs& a, hipStream_t s) {
+static int run_col_partial(const ColGeom& g, const ColArgs& a, hipStream_t s, int ngroups = 1) {
   if (g.vw == 4)
-    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 4>), dim3(g.nblk, g.ncol), dim3(256), 0, s, g, a);
+    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 4>), dim3(g.nblk, g.ncol, ngroups), dim3(256), 0, s, g, a);
   else
-    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 1>), dim3(g.nblk, g.ncol), dim3(256), 0, s, g, a);
+    hipLaunchKernelGGL((col_partial_kernel<T, MODE, 1>), dim3(g.nblk, g.ncol, ngroups), dim3(256), 0, s, g, a);
   TDG_HIP_LAUNCH_CHECK("col_partial");
   return TDG_OK;
 }
@@ -536,6 +547,46 @@ extern "C" int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, con
                          leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
   })
   TDG_HIP_LAUNCH_CHECK("bn_fwd");
+  return TDG_OK;
+}
+
+// Batch norm + activation of `ngroups` batches that lie behind each other in one tensor, each with ITS OWN batch statistics: the
+// generator passes of the n_disc_train critic steps of an iteration run as one pass over n_disc_train x B latent vectors
+// (models/gan.py: the generator's variables do not change between them), and ops/layers.py:103,144 normalises per run of the op,
+// i.e. per batch of B.  Three launches for all groups (blockIdx.z / .y = group); `pre` may be null (no backward pass follows).
+extern "C" int tdg_bn_fwd_groups(int dtype, const void* u, int rows_per_group, int ngroups, int c, int cs, const float* beta,
+                                 float eps, int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(u && beta && h && stats && workspace, "tdg_bn_fwd_groups: null pointer");
+  TDG_CHECK_ARG(rows_per_group > 0 && ngroups > 0 && ngroups <= 65535 && c > 0 && cs >= c && h_cs >= c,
+                "tdg_bn_fwd_groups: bad shape rows=%d groups=%d c=%d cs=%d h_cs=%d", rows_per_group, ngroups, c, cs, h_cs);
+  TDG_CHECK_ARG((long long)rows_per_group * ngroups <= 0x7fffffffLL, "tdg_bn_fwd_groups: %d x %d rows", rows_per_group, ngroups);
+  TDG_CHECK_ARG(!pre || h_cs == cs || pre != h, "tdg_bn_fwd_groups: pre and h alias with different strides");
+  if (workspace_bytes < (size_t)ngroups * tdg_bn_workspace_bytes(rows_per_group, c)) { tdg_set_error("tdg_bn_fwd_groups: workspace too small"); return TDG_EWORKSPACE; }
+  hipStream_t s = (hipStream_t)stream;
+  const int es = tdg_dtype_size(dtype);
+  // the groups' first rows must keep the alignment the vector width was chosen for
+  const bool grp_al = ((size_t)rows_per_group * cs * es) % (4 * es) == 0 && ((size_t)rows_per_group * h_cs * es) % (4 * es) == 0;
+  const ColGeom g = col_geom(rows_per_group, c, cs, u, nullptr, es, grp_al);
+  ColArgs a; memset(&a, 0, sizeof(a));
+  a.x = u; a.partial = static_cast<float*>(workspace);
+  FinArgs f; memset(&f, 0, sizeof(f));
+  f.partial = a.partial; f.nblk = g.nblk; f.C = c; f.rows = rows_per_group; f.x0 = u; f.x0_group = (long long)rows_per_group * cs;
+  f.eps = eps; f.out0 = stats;
+  const ColGeom ga = col_geom(rows_per_group, c, cs, u, (const void*)((uintptr_t)pre | (uintptr_t)h), es, grp_al && h_cs % 4 == 0);
+  const dim3 agrid(apply_row_blocks(ga), ga.ncol, ngroups);
+  DISPATCH_T(dtype, {
+    int rc = run_col_partial<T, COL_BN_STATS>(g, a, s, ngroups);
+    if (rc) return rc;
+    launch_col_finalize<T, FIN_BN_STATS>(f, s, ngroups);
+    if (ga.vw == 4)
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 4>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
+    else
+      hipLaunchKernelGGL((bn_fwd_apply_kernel<T, 1>), agrid, dim3(256), 0, s, ga, static_cast<const T*>(u), beta, stats, act,
+                         leak, static_cast<T*>(pre), static_cast<T*>(h), h_cs);
+  })
+  TDG_HIP_LAUNCH_CHECK("bn_fwd_groups");
   return TDG_OK;
 }
 

@@ -3611,7 +3611,7 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     if (veca && bn == 208 && dma_mode == 1 && !getenv("TDG_DMA_BM") && !getenv("TDG_DMA_NW")) {
       const long long per = (long long)tdg_ceil_div(a.N, 208) * a.nclasses;
       const double c192 = (double)tdg_ceil_div(per * tdg_ceil_div(mmax, 192), 256) * 192 / 1.0;
-      const double c128 = (double)tdg_ceil_div(per * tdg_ceil_div(mmax, 128), 256) * 128 / 0.85;
+      const double c128 = (double)tdg_ceil_div(per * tdg_ceil_div(mmax, 128), 256) * 128 / 0.75;   // in the step: 890 - 915 TF against 1170 - 1370
       const int pbm = getenv("TDG_PATCH_BM") ? atoi(getenv("TDG_PATCH_BM")) : 0;            // diagnostics: force a row tile
       const bool want128 = pbm ? pbm == 128 : c128 < c192 - 1e-9;
       if (want128 && plan_fwd_patch<128>(a, mmax)) return launch_fwd_patch<128, 208>(a, mmax, s);

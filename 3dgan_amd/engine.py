@@ -280,8 +280,12 @@ class SeqNet:
     """
 
     def __init__(self, net, capacity, in_shape, dtype, device, store, n_bn_passes=1, need_input_grad=False,
-                 tangent_capacity=0, ws=None, out_act=None, out_grad=None):
+                 tangent_capacity=0, ws=None, out_act=None, out_grad=None, forward_only=False):
+        """forward_only: no gradient buffers are bound (a net that only ever runs forward / forward_groups)."""
         self.net, self.cap, self.dtype, self.device, self.store = net, capacity, dtype, device, store
+        self.forward_only = forward_only
+        if forward_only and (need_input_grad or tangent_capacity or out_grad is not None):
+            raise ValueError('a forward-only net has no gradient buffers')
         self.ws = ws or K.Workspace(device)
         self._pack_jobs = None
         self.n_bn_passes = n_bn_passes
@@ -319,9 +323,9 @@ class SeqNet:
                 if (L.h.n, L.h.h, L.h.w, L.h.c) != (capacity * rpi, oh, ow, oc):
                     raise ValueError('out_act does not match the last layer output')
                 L.pre = L.h.like() if spec.normed and spec.kind != 'residual' else None       # batch norm: the normalised pre-activation; instance norm: the conv output
-                L.delta = L.h.like()
+                L.delta = L.h.like() if not forward_only else None
                 sep = spec.normed or spec.kind == 'residual' or L.act.code in (K.ACT_TANH, K.ACT_SIGMOID)
-                L.gout = L.h.like() if sep else L.delta
+                L.gout = (L.h.like() if sep else L.delta) if not forward_only else None
                 if last and out_grad is not None:
                     if not sep:
                         L.delta = out_grad
@@ -404,7 +408,47 @@ class SeqNet:
         if len(self._pack_jobs):
             K.pack_all(self._pack_jobs)
 
+    def share_filters(self, other):
+        """Use `other`'s packed GEMM operands (a second binding of the same variables at another capacity): the packed
+        layouts depend on the filter geometry only, so neither net packs twice and this one never repacks."""
+        for L, O in zip(self.layers, other.layers):
+            if L.rowdot:
+                continue
+            if L.spec.kind == 'residual' or L.spec is not O.spec:
+                raise NotImplementedError('share_filters: layer %s' % L.spec.name)
+            if (L.conv.fwd_bytes, L.conv.bwd_bytes) != (O.conv.fwd_bytes, O.conv.bwd_bytes):
+                raise ValueError('layer %s: packed filter sizes differ between the two bindings' % L.spec.name)
+            L.conv.w_fwd, L.conv.w_bwd = O.conv.w_fwd, O.conv.w_bwd
+        self._pack_jobs = ()
+
     # -- forward -----------------------------------------------------------------------------------
+    def forward_groups(self, ngroups, n):
+        """forward(keep_pre=False) of `ngroups` batches of n images that lie behind each other (images [0, ngroups * n)):
+        every conv is ONE GEMM over all of them, every batch norm takes its statistics per batch (tdg_bn_fwd_groups) --
+        what ngroups separate forward() calls compute, with the GEMMs at ngroups times the rows."""
+        if ngroups * n > self.cap:
+            raise ValueError('%d x %d images, capacity %d' % (ngroups, n, self.cap))
+        for L in self.layers:
+            if L.rowdot or L.spec.kind == 'residual' or L.spec.use_in:
+                raise NotImplementedError('forward_groups: layer %s' % L.spec.name)
+            rn = ngroups * n * L.rpi
+            bias = self.store[L.bname]
+            if L.spec.use_bn:
+                epi, target = K.epilogue(bias=bias), L.pre
+            else:
+                epi, target = K.epilogue(bias=bias, act=L.act.code, leak=L.act.leak), L.h
+            if L.spec.kind == 'deconv2d':
+                L.conv.bwd_data(L.inp.ptr(0), target.ptr(0), rn, epi)
+            else:
+                L.conv.fwd(L.inp.ptr(0), target.ptr(0), rn, epi)
+            if L.spec.use_bn:
+                C = L.spec.out_size
+                if getattr(L, 'bn_stats_groups', None) is None or L.bn_stats_groups.numel() < ngroups * 2 * C:
+                    L.bn_stats_groups = torch.zeros(ngroups * 2 * C, dtype=torch.float32, device=self.device)
+                K.bn_fwd_groups(self.ws, L.pre, C, self.store[L.bn_names[0]], L.act.code, None, L.h, L.bn_stats_groups,
+                                n * L.rpi * L.h.h * L.h.w, ngroups, leak=L.act.leak)
+        return self.layers[-1].h
+
     def forward(self, img0, n, bn_pass=0, keep_pre=True):
         """Layers on images [img0, img0+n).  Returns the last layer's output (Act or f32 scores).  keep_pre=False: no backward
         pass will follow, so batch-norm layers skip writing their normalised pre-activation (only its activation)."""

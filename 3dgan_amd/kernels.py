@@ -302,6 +302,14 @@ def bn_fwd(ws, u, c, beta, act, pre, h, stats, rows=None, leak=0.2, eps=1e-3, u_
               pre_ptr or pre.ptr(), h_ptr or h.ptr(), h.cs, ptr(stats), ptr(w), w.numel(), stream())
 
 
+def bn_fwd_groups(ws, u, c, beta, act, pre, h, stats, rows_per_group, ngroups, leak=0.2, eps=1e-3, u_ptr=None, pre_ptr=None, h_ptr=None):
+    """bn_fwd over ngroups batches behind each other, each with its own statistics (stats: [ngroups][2][c]); pre=None: only h."""
+    need = ngroups * _lib.load().tdg_bn_workspace_bytes(rows_per_group, c)
+    w = ws.ensure(need)
+    _lib.call('tdg_bn_fwd_groups', u.dtype, u_ptr or u.ptr(), rows_per_group, ngroups, c, u.cs, ptr(beta), eps, act, leak,
+              (pre_ptr or pre.ptr()) if pre is not None else None, h_ptr or h.ptr(), h.cs, ptr(stats), ptr(w), w.numel(), stream())
+
+
 def bn_bwd(ws, dh, pre, c, beta, stats, act, du, dbeta, rows=None, leak=0.2, beta_acc=0.0,
            dh_ptr=None, pre_ptr=None, du_ptr=None, dbias=None, dbias_acc=0.0):
     """dbias: also the bias gradient of the conv in front of the batch norm (column sums of du), from the same pass."""

@@ -111,6 +111,16 @@ class GanReplica(engine.GraphRunner):
         # the generator writes straight into slot 1 and reads dL/dg from the same slot of D.dx
         self.G = engine.SeqNet(gnet, B, (1, 1, L), dt, dev, self.g_store, ws=self.ws,
                                out_act=self.D.x.view(B, B), out_grad=self.D.dx.view(B, B))
+        # the generator passes of an iteration's n_disc_train critic steps run through the SAME generator variables
+        # (models/gan.py:150-155,169-173): a second, forward-only binding takes them as one pass over n_disc_train x B
+        # latent vectors with per-batch batch-norm statistics (_generate_ahead); each critic step copies its batch into slot 1
+        nd = int(getattr(args, 'n_disc_train', 1) or 1)
+        self.G_ahead, self._ahead = None, None
+        if self.model != 'gan' and nd > 1 and os.environ.get('TDG_G_AHEAD', '1') != '0':        # (=0, diagnostics: one pass per critic step)
+            self.n_ahead = nd
+            self.G_ahead = engine.SeqNet(gnet, nd * B, (1, 1, L), dt, dev, self.g_store, ws=self.ws, forward_only=True,
+                                         out_act=K.Act(nd * B, h, w, c, dt, dev, cs=self.D.x.cs))
+            self.G_ahead.share_filters(self.G)
         self.D.declare_variables()
         self.G.declare_variables()
         self.d_store.allocate()
@@ -174,6 +184,35 @@ class GanReplica(engine.GraphRunner):
     def _generate(self, backward_follows=True):
         self.sess.random_normal(self.G.x, self.B, 'z')                 # models/gan.py:246
         self.G.forward(0, self.B, keep_pre=backward_follows)           # g lands in D.x slot 1
+
+    def _generate_ahead(self):
+        """The generator passes of the next n_disc_train critic steps: one draw of n_disc_train x B latent vectors, one
+        batched forward pass, batch norm per batch of B (what n_disc_train runs of d_train_op compute one by one)."""
+        self.sess.random_normal(self.G_ahead.x, self.n_ahead * self.B, 'z')
+        self.G_ahead.forward_groups(self.n_ahead, self.B)
+
+    def _ahead_ok(self, n_steps):
+        """Tests that inject or stage ONE batch of z per critic step keep the pass-per-step form."""
+        if self.G_ahead is None or n_steps != self.n_ahead or self.sess.inject.get('z'):
+            return False
+        staged = self.sess.staged.get('z')
+        return staged is None or staged.numel() >= self.n_ahead * self.B * self.G_ahead.x.image_elems
+
+    def _begin_ahead(self, n_steps):
+        """Start of an iteration of n_steps critic steps: their generator passes, if this iteration may take them ahead."""
+        ahead = self._ahead_ok(n_steps)
+        if ahead:
+            self._run('g_ahead', self._generate_ahead)
+        return ahead
+
+    def _stage_ahead(self):
+        """Critic step number self._ahead of the iteration: its g (generated ahead) into slot 1.  Returns the suffix of the
+        captured bodies' names: a body either holds the generator pass or it does not."""
+        if self._ahead is None:
+            return ''
+        B = self.B
+        self.D.x.view(B, B).buf.copy_(self.G_ahead.layers[-1].h.view(self._ahead * B, B).buf)
+        return '+ahead'
 
     def samples(self, n):
         """(inputs, fake) as float32 NHWC in [-1, 1]: the first n images of the staged real batch and of a fresh
@@ -263,14 +302,15 @@ class GanReplica(engine.GraphRunner):
         the bucket follows.  One replica: a single captured body, no exchange."""
         self._load_real(x01)
         sess, store = self.sess, self.d_store
+        tag = self._stage_ahead()
         if sess.world_size > 1 and self.iwgan and os.environ.get('TDG_DSPLIT', '1') != '0':      # (TDG_DSPLIT=0, diagnostics: one body, one exchange)
             lo, hi = self.big_slice()
-            self._run('d_grads_a', self._d_grads_a)
+            self._run('d_grads_a' + tag, self._d_grads_a)
             self._scale = sess.allreduce_split(store.grads, lo, hi, between=lambda: self._run('d_grads_b', self._d_grads_b))
             sess.assert_finite(store, 'd_step')                       # after EVERY slice is summed: a NaN/Inf on one
                                                                       # replica is in every replica's bucket by now
         else:
-            self._run('d_grads', self._d_grads)
+            self._run('d_grads' + tag, self._d_grads)
             sess.assert_finite(store, 'd_step')
             self._scale = average_gradients(sess, store)              # models/gan.py:77 (RCCL, outside the graphs)
         self._run('d_apply', self._d_apply)
@@ -300,7 +340,8 @@ class GanReplica(engine.GraphRunner):
         B, R = self.B, self.B * self.rows_per_image
         self._clip_critic()
         self._rescale_real()
-        self._generate(backward_follows=False)                         # the critic step does not back-propagate into G
+        if self._ahead is None:
+            self._generate(backward_follows=False)                     # the critic step does not back-propagate into G
         if self.iwgan:
             self._interpolate()
         scores = self._d_forward(0, self.nslots)
@@ -448,8 +489,13 @@ class GanReplica(engine.GraphRunner):
         if self.model == 'gan':                                       # _train_gan: one run of both train ops
             self.gan_step(self.x_source.next_batch())
             return self.losses()
-        for _ in range(args.n_disc_train):
-            self.d_step(self.x_source.next_batch())
+        ahead = self._begin_ahead(args.n_disc_train)
+        try:
+            for i in range(args.n_disc_train):
+                self._ahead = i if ahead else None
+                self.d_step(self.x_source.next_batch())
+        finally:
+            self._ahead = None
         self.g_step(self.x_source.next_batch())
         return self.losses()
 

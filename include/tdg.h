@@ -184,6 +184,14 @@ size_t tdg_bn_workspace_bytes(int rows, int c);
 int tdg_bn_fwd(int dtype, const void* u, int rows, int c, int cs, const float* beta, float eps,
                int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
                size_t workspace_bytes, void* stream);
+/* tdg_bn_fwd over `ngroups` batches of rows_per_group rows that lie behind each other in u / pre / h, each normalised with
+ * ITS OWN batch statistics (stats [ngroups][2][c]; workspace >= ngroups * tdg_bn_workspace_bytes): the generator passes of
+ * the n_disc_train critic runs of one iteration (models/gan.py:150-155,169-173 -- `sess.run(d_train_op)` n_disc_train times,
+ * each drawing its own z through the same generator variables) taken as ONE pass; batch_norm (ops/layers.py:103,144)
+ * normalises per run, i.e. per group.  pre may be null (no backward pass follows). */
+int tdg_bn_fwd_groups(int dtype, const void* u, int rows_per_group, int ngroups, int c, int cs, const float* beta,
+                      float eps, int act, float leak, void* pre, void* h, int h_cs, float* stats, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* ---- instance norm of the gen-2 layer surface (hem/ops/images.py:73-89; `use_instance_norm=True`,
  *      hem/ops/layers.py:123,200): per (image, channel) moments over the hw positions, biased variance, eps 1e-3,
  *      learned per-channel scale (init 1) and shift (init 0); fused with the layer's activation.

@@ -108,16 +108,26 @@ def _phases(model, rep):
         return ([(dg, rep.d_store, lambda: rep._run('d_apply', rep._d_apply)),
                  (gg, rep.g_store, lambda: rep._run('g_apply', rep._g_apply))], rep.report)
 
-    def dgr(b):
-        rep._load_real(b)
-        rep._run('d_grads', rep._d_grads)
+    nd = rep.args.n_disc_train
+
+    def dgr(i):
+        def grads(b):                                                 # what train_func + d_step do around the critic's gradient body
+            rep._load_real(b)
+            if i == 0:
+                rep._iter_ahead = rep._begin_ahead(nd)                # the iteration's generator passes, taken ahead
+            rep._ahead = i if rep._iter_ahead else None
+            try:
+                rep._run('d_grads' + rep._stage_ahead(), rep._d_grads)
+            finally:
+                rep._ahead = None
+        return grads
 
     def ggr(b):
         rep._load_real(b)
         rep._run('g_grads', rep._g_grads)
-    d = (dgr, rep.d_store, lambda: rep._run('d_apply', rep._d_apply))
+    d = [(dgr(i), rep.d_store, lambda: rep._run('d_apply', rep._d_apply)) for i in range(nd)]
     g = (ggr, rep.g_store, lambda: rep._run('g_apply', rep._g_apply))
-    return [d] * rep.args.n_disc_train + [g], (lambda b: rep.losses())
+    return d + [g], (lambda b: rep.losses())
 
 
 def _save(out_path, rep, losses, extra=None):
