@@ -2629,77 +2629,91 @@ struct PackArgs {
   int rows, ntaps, C, Ceff, Kp;
   int CK;                // channels of a tap per K slice (= Ceff: plain (tap, channel) order; IgArgs.fd_ck otherwise)
   int stride_tap, stride_row, stride_ch;
+  FastDiv fd_slice, fd_ck;   // / (ntaps * CK), / CK   (pack_finish)
   unsigned char tap_ids[IG_MAX_TAPS];
 };
+static inline void pack_finish(PackArgs* a) {
+  a->fd_slice = make_fastdiv((uint32_t)(a->ntaps * a->CK));
+  a->fd_ck = make_fastdiv((uint32_t)a->CK);
+}
 
-// one (row tile of 32, k tile of PACK_TK = 64) with an LDS transpose so both sides coalesce; 8 elements per thread,
-// two consecutive k per store (the 32 x 32 tile with 2-byte stores ran at 1.7 TB/s)
+// PACK_RT (row tile of 32, k tile of PACK_TK = 64) tiles per workgroup, each with an LDS transpose so both sides coalesce; 8
+// elements per thread and tile, two consecutive k per store (the 32 x 32 tile with 2-byte stores ran at 1.7 TB/s).  The K index ->
+// (slice, tap, channel) -> master offset of a thread's k's does not depend on the row tile: it is computed once per workgroup
+// (round 4: one tile per workgroup with two runtime divisions per element packed the critic's 10 M parameters in 38 us =
+// 2.1 TB/s -- 10 127 workgroups of 8 elements per thread).
 #define PACK_TK 64
+#define PACK_RT 4
 template <typename T>
-__device__ __forceinline__ void pack_tile(const PackArgs& a, int bx, int by, float (*tile)[33]) {
-  const int k0 = bx * PACK_TK, r0 = by * 32;
+__device__ __forceinline__ void pack_tiles(const PackArgs& a, int bx, int byg, float (*tile)[33]) {
+  const int k0 = bx * PACK_TK;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const bool row_fast = a.stride_row == 1;                  // which source index is contiguous
   const int kmax = a.ntaps * a.Ceff;
+  // master offset of K index k without its row term; -1: a zero (K padding, channel padding)
+  auto k_src = [&](int k) -> int {
+    if (k >= kmax) return -1;
+    const int sl = (int)fd_div((unsigned)k, a.fd_slice), kr = k - sl * (a.ntaps * a.CK);
+    const int ti = (int)fd_div((unsigned)kr, a.fd_ck), c = sl * a.CK + (kr - ti * a.CK);
+    return c < a.C ? (int)a.tap_ids[ti] * a.stride_tap + c * a.stride_ch : -1;
+  };
+  int ks[PACK_TK / 8];
   if (row_fast) {                                           // lanes walk rows; k = k0 + ty + 8p
 #pragma unroll
-    for (int p = 0; p < PACK_TK / 8; ++p) {
-      const int i = ty + 8 * p, r = r0 + tx, k = k0 + i;
-      float v = 0.f;
-      if (r < a.rows && k < kmax) {
-        const int sl = k / (a.ntaps * a.CK), kr = k - sl * (a.ntaps * a.CK);
-        const int ti = kr / a.CK, c = sl * a.CK + (kr - ti * a.CK);
-        if (c < a.C) v = a.w[(size_t)a.tap_ids[ti] * a.stride_tap + (size_t)r * a.stride_row + (size_t)c * a.stride_ch];
-      }
-      tile[i][tx] = v;                                      // tile[k_local][r_local]
-    }
+    for (int p = 0; p < PACK_TK / 8; ++p) ks[p] = k_src(k0 + ty + 8 * p);
   } else {                                                  // lanes walk k (two halves of the k tile); rows = r0 + ty + 8p
 #pragma unroll
-    for (int h = 0; h < PACK_TK / 32; ++h) {
-      const int kl = h * 32 + tx, k = k0 + kl;
-      const bool kok = k < kmax;
-      const int sl = kok ? k / (a.ntaps * a.CK) : 0, kr = k - sl * (a.ntaps * a.CK);
-      const int ti = kok ? kr / a.CK : 0, c = sl * a.CK + (kr - ti * a.CK);
-      const size_t base = (size_t)a.tap_ids[ti] * a.stride_tap + (size_t)c * a.stride_ch;
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const int i = ty + 8 * p, r = r0 + i;
-        float v = 0.f;
-        if (kok && c < a.C && r < a.rows) v = a.w[base + (size_t)r * a.stride_row];
-        tile[kl][i] = v;
-      }
-    }
+    for (int h = 0; h < PACK_TK / 32; ++h) ks[h] = k_src(k0 + h * 32 + tx);
   }
-  __syncthreads();
   T* out = static_cast<T*>(a.out);
+  for (int s = 0; s < PACK_RT; ++s) {
+    const int r0 = (byg * PACK_RT + s) * 32;
+    if (r0 >= a.rows) break;                                // (uniform)
+    if (row_fast) {
+      const int r = r0 + tx;
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int rl = ty + 8 * p;
-    const int r = r0 + rl, k = k0 + 2 * tx;
-    if (r >= a.rows || k >= a.Kp) continue;
-    const float v0 = tile[2 * tx][rl], v1 = tile[2 * tx + 1][rl];
-    if (k + 1 < a.Kp && ((a.Kp & 1) == 0)) {                // (row pitch even: the pair is aligned)
-      if constexpr (sizeof(T) == 2) {
-        typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<bf16x2_t*>(out + (size_t)r * a.Kp + k) = bf16x2_t{(bf16_t)v0, (bf16_t)v1};
-      } else {
-        *reinterpret_cast<float2*>(out + (size_t)r * a.Kp + k) = float2{v0, v1};
-      }
+      for (int p = 0; p < PACK_TK / 8; ++p)
+        tile[ty + 8 * p][tx] = (ks[p] >= 0 && r < a.rows) ? a.w[(size_t)ks[p] + (size_t)r] : 0.f;     // tile[k_local][r_local]
     } else {
-      out[(size_t)r * a.Kp + k] = from_f32<T>(v0);
-      if (k + 1 < a.Kp) out[(size_t)r * a.Kp + k + 1] = from_f32<T>(v1);
+#pragma unroll
+      for (int h = 0; h < PACK_TK / 32; ++h)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const int i = ty + 8 * p, r = r0 + i;
+          tile[h * 32 + tx][i] = (ks[h] >= 0 && r < a.rows) ? a.w[(size_t)ks[h] + (size_t)r * a.stride_row] : 0.f;
+        }
     }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rl = ty + 8 * p;
+      const int r = r0 + rl, k = k0 + 2 * tx;
+      if (r >= a.rows || k >= a.Kp) continue;
+      const float v0 = tile[2 * tx][rl], v1 = tile[2 * tx + 1][rl];
+      if (k + 1 < a.Kp && ((a.Kp & 1) == 0)) {                // (row pitch even: the pair is aligned)
+        if constexpr (sizeof(T) == 2) {
+          typedef bf16_t bf16x2_t __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<bf16x2_t*>(out + (size_t)r * a.Kp + k) = bf16x2_t{(bf16_t)v0, (bf16_t)v1};
+        } else {
+          *reinterpret_cast<float2*>(out + (size_t)r * a.Kp + k) = float2{v0, v1};
+        }
+      } else {
+        out[(size_t)r * a.Kp + k] = from_f32<T>(v0);
+        if (k + 1 < a.Kp) out[(size_t)r * a.Kp + k + 1] = from_f32<T>(v1);
+      }
+    }
+    __syncthreads();
   }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
   __shared__ float tile[PACK_TK][33];
-  pack_tile<T>(a, blockIdx.x, blockIdx.y, tile);
+  pack_tiles<T>(a, blockIdx.x, blockIdx.y, tile);
 }
 
 // several packing jobs in one launch: block b belongs to the job j with start[j] <= b < start[j+1]
-#define PACK_MULTI_MAX 36
+#define PACK_MULTI_MAX 32
 struct PackMultiArgs {
   int njobs;
   int start[PACK_MULTI_MAX + 1];
@@ -2716,7 +2730,7 @@ __global__ void __launch_bounds__(256) pack_multi_kernel(const PackMultiArgs m) 
   const int local = blockIdx.x - m.start[j];
   const int gx = (a.Kp + PACK_TK - 1) / PACK_TK;
   const int by = local / gx;
-  pack_tile<T>(a, local - by * gx, by, tile);
+  pack_tiles<T>(a, local - by * gx, by, tile);
 }
 
 // ============================================================================================
@@ -3687,6 +3701,10 @@ int launch_fwd(IgArgs& a, bool veca, int bn, hipStream_t s) {
     const int bnt = a.N <= 112 ? 112 : 128;
     const long long per = (long long)tdg_ceil_div(a.N, bnt) * a.nclasses;
     const long long t256 = per * tdg_ceil_div(mmax, 256), t128 = per * tdg_ceil_div(mmax, 128);
+    // (TWO workgroups per CU -- 128-row tiles on a 2-stage ring, 60 / 64 KB of LDS, < 90 registers -- so that one workgroup's
+    //  barrier waits, prologue and epilogue lie under the other's MFMAs: measured 755 vs 827 TF (128 columns, pix2pix / VAE) and
+    //  638 vs 709 TF (112 columns, the generator's dc3 at 2560 images): the smaller tile's intake per FLOP costs more than the
+    //  overlap returns.  Not kept.)
     const double c256 = (double)tdg_ceil_div(t256, 256) * 256, c128 = (double)tdg_ceil_div(t128, 256) * 128 / 0.85;
     if (bnt == 112) return c128 < c256 ? launch_fwd_dma<T, 128, 112, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 112, 3>(a, mmax, s);
     return c128 < c256 ? launch_fwd_dma<T, 128, 128, 3>(a, mmax, s) : launch_fwd_dma<T, 256, 128, 3>(a, mmax, s);
@@ -4081,6 +4099,7 @@ static void build_pack_fwd(const TdgConvDesc* d, const float* w, void* packed, P
   int ord[IG_MAX_TAPS];
   fwd_tap_order(d, ord);
   for (int t = 0; t < a->ntaps; ++t) a->tap_ids[t] = (unsigned char)ord[t];
+  pack_finish(a);
 }
 
 // one job per non-empty parity class; returns the count (the fused-class form is not handled here)
@@ -4107,6 +4126,7 @@ static int build_pack_bwd(const TdgConvDesc* d, const float* w, void* packed, Pa
     a.stride_row = d->k;    // row = big-side channel
     a.stride_ch = 1;        // K channel = small-side channel (contiguous in the master)
     for (int t = 0; t < a.ntaps; ++t) a.tap_ids[t] = (unsigned char)cls[i].tap_ids[t];
+    pack_finish(&a);
     off += (size_t)a.rows * a.Kp * es;
   }
   return n;
@@ -4126,10 +4146,11 @@ static void build_pack_col2im(const TdgConvDesc* d, const Col2imPlan& cp, const 
   a->stride_row = d->k;
   a->stride_ch = 1;
   a->tap_ids[0] = 0;
+  pack_finish(a);
 }
 
 static int launch_pack_one(const PackArgs& a, int dtype, hipStream_t s) {
-  dim3 grid(tdg_ceil_div(a.Kp, PACK_TK), tdg_ceil_div(a.rows, 32));
+  dim3 grid(tdg_ceil_div(a.Kp, PACK_TK), tdg_ceil_div(a.rows, 32 * PACK_RT));
   if (dtype == TDG_BF16)
     hipLaunchKernelGGL(pack_filter_kernel<bf16_t>, grid, dim3(256), 0, s, a);
   else
@@ -4214,7 +4235,7 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
       if (rc) return rc;
     }
     m.job[m.njobs] = a;
-    m.start[m.njobs + 1] = m.start[m.njobs] + tdg_ceil_div(a.Kp, PACK_TK) * tdg_ceil_div(a.rows, 32);
+    m.start[m.njobs + 1] = m.start[m.njobs] + tdg_ceil_div(a.Kp, PACK_TK) * tdg_ceil_div(a.rows, 32 * PACK_RT);
     ++m.njobs;
     return TDG_OK;
   };
