@@ -223,7 +223,9 @@ static inline ColGeom col_geom(int rows, int C, int cs, const void* p0 = nullptr
   while (cl < cv && cl < 64) cl <<= 1;
   g.CL = cl;
   g.ncol = (cv + cl - 1) / cl;
-  int nblk = (rows + 127) / 128;
+  // wide tensors (>= 8 column chunks: the flattened 4 x 4 x 800 input of the critic's fc2) with few rows: 32-row blocks, or the grid
+  // is 1 - 2 workgroups per CU (1024 rows x 12800 columns: 8 x 50 workgroups, 17 us = 1.5 TB/s)
+  int nblk = g.ncol >= 8 ? (rows + 31) / 32 : (rows + 127) / 128;
   const int cap = g.ncol >= 8 ? 32 : (g.ncol >= 2 ? 512 : 1024);   // ~4 workgroups per CU for the big single-chunk tensors
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
