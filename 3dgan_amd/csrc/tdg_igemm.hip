@@ -363,10 +363,6 @@ __global__ void __launch_bounds__(256, 2) igemm_fwd_kernel(const IgArgs args) {
 // x 8 physical chunks, lane l supplies logical chunk (l&7) ^ ((row>>1)&7).  Instructions are dealt
 // to waves by parity of their index so that this XOR term is one constant per lane.
 // ============================================================================================
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void store_tile_with_col_partials(const char* sE, const long long* sPix, float* sRed, const float* sBias, int tid,
-                                                             int m0, int n0, int M, int tile_m, const IgArgs& args, const IgClass& cl);   // (defined beside staged_epilogue_bf16)
-
 // Per-lane state of the LDS-DMA loader of igemm_fwd_dma_kernel.  A K step's loads are NP single
 // wave-instructions ("pieces": NAJ of the gathered operand, NBJ of the packed filter; every wave issues
 // the same number, a wave with one filter piece less issues an out-of-range one into don't-care rows), so
@@ -839,12 +835,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) igemm_fwd_dma_kernel
       });
       __syncthreads();
       TDG_STAMP(ph2);
-      constexpr bool COLFAST = BM * PE + BM * 8 + NTHR * 64 <= NS * STAGE;    // room for the row groups' partial sums
-      if (COLFAST && args.col_partial) {
-        if constexpr (COLFAST)
-          store_tile_with_col_partials<BM, BN, NTHR>(sE, sPix, reinterpret_cast<float*>(smem + BM * PE + BM * 8), sBias, tid, m0, n0, M, tile_m, args, cl);
-        return;
-      }
       const float mlow = mask_low(mmode, leak);
       // chunk c = tid + NTHR * it of the tile.  The mask pieces of ALL the thread's chunks are requested before the
       // first one is used (a load -> multiply -> store chain per chunk paid the memory latency NIT times over)
@@ -1034,91 +1024,6 @@ __device__ __forceinline__ bf16x8 pt_lds_frag(int byte_addr) {
   return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>((__attribute__((address_space(3))) char*)nullptr + byte_addr);
 }
 
-// Stores of a bf16 tile staged in LDS (sE, row pitch BN * 2 + 16; sPix: the rows' element offsets in `out`, -1 past M) WITH the
-// column partials of what is stored (TdgEpilogue.col_partial).  Every thread calls it; ends behind its own barrier.
-template <int BM, int BN, int NTHR>
-__device__ __forceinline__ void store_tile_with_col_partials(const char* sE, const long long* sPix, float* sRed, const float* sBias, int tid,
-                                                             int m0, int n0, int M, int tile_m, const IgArgs& args, const IgClass& cl) {
-  using T = bf16_t;
-  constexpr int PE = BN * 2 + 16, CPR = BN * 2 / 16;
-  const int N = args.N;
-  T* out = static_cast<T*>(args.out);
-  const T* msk = static_cast<const T*>(args.mask_src);
-  const int mmode = args.mask_mode;
-  const float mlow = mask_low(mmode, args.leak);
-  {
-    // ---- with column partials: a thread keeps ONE 8-column chunk (cc) and walks rows rg, rg + NRG, ... -- its eight column sums
-    // (and sums of squares) of the values it stores stay in registers, NRG row groups meet in LDS once.  (Round 4: the row-major
-    // walk below followed by a second pass of 96 two-byte LDS reads per thread over the stored tile cost 31 us of c2 backward-data's
-    // 346 us and needed the masked values written back to LDS.)  Fixed summation order: deterministic.
-    constexpr int NRG = NTHR / CPR, NITC = (BM + NRG - 1) / NRG;
-    const int cc = tid % CPR, rg = tid / CPR;
-    const int n = n0 + cc * 8;
-    const bool on = rg < NRG && n < N;
-    const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW * (cl.nbh * cl.nbw > 1 ? cl.nbh * cl.nbw : 1)) : M;
-    const int rows_valid = max(0, min(BM, mlim - m0));
-    const bool bnm = args.col_mode == TDG_COL_BN;
-    long long pp[NITC];
-    bf16x8 mv[NITC];
-#pragma unroll
-    for (int it = 0; it < NITC; ++it) {
-      const int row = rg + NRG * it;
-      const long long p = (on && row < BM) ? sPix[row] : -1;
-      pp[it] = p;
-      mv[it] = bf16x8{(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f};
-      if (mmode != TDG_MASK_NONE && p >= 0) {
-        if (n + 8 <= N) {
-          mv[it] = *reinterpret_cast<const bf16x8*>(msk + p + n);
-        } else {
-          const bf16x4 h = *reinterpret_cast<const bf16x4*>(msk + p + n);
-          mv[it][0] = h[0]; mv[it][1] = h[1]; mv[it][2] = h[2]; mv[it][3] = h[3];
-        }
-      }
-    }
-    float piv[8], s0[8], s1[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { piv[e] = (bnm && on) ? sBias[cc * 8 + e] : 0.f; s0[e] = 0.f; s1[e] = 0.f; }
-#pragma unroll
-    for (int it = 0; it < NITC; ++it) {
-      const long long p = pp[it];
-      if (p < 0) continue;
-      const int row = rg + NRG * it;
-      bf16x8 v = *reinterpret_cast<const bf16x8*>(sE + row * PE + cc * 16);
-      if (mmode != TDG_MASK_NONE) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[it][e] > 0.f ? 1.f : mlow));
-      }
-      if (n + 8 <= N) {
-        *reinterpret_cast<bf16x8*>(out + p + n) = v;
-      } else {
-        *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
-      }
-      if (row < rows_valid) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - piv[e]; s0[e] += f; s1[e] += f * f; }
-      }
-    }
-    // sRed: [NRG][2][CPR * 8] floats = NTHR * 64 bytes
-    if (rg < NRG) {
-      float* r0p = sRed + (size_t)(rg * 2 + 0) * (CPR * 8) + cc * 8;
-      float* r1p = sRed + (size_t)(rg * 2 + 1) * (CPR * 8) + cc * 8;
-      *reinterpret_cast<f32x4*>(r0p) = f32x4{s0[0], s0[1], s0[2], s0[3]};
-      *reinterpret_cast<f32x4*>(r0p + 4) = f32x4{s0[4], s0[5], s0[6], s0[7]};
-      *reinterpret_cast<f32x4*>(r1p) = f32x4{s1[0], s1[1], s1[2], s1[3]};
-      *reinterpret_cast<f32x4*>(r1p + 4) = f32x4{s1[4], s1[5], s1[6], s1[7]};
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < N) {
-      float t0 = 0.f, t1 = 0.f;
-#pragma unroll 4
-      for (int g = 0; g < NRG; ++g) { t0 += sRed[(size_t)(g * 2 + 0) * (CPR * 8) + tid]; t1 += sRed[(size_t)(g * 2 + 1) * (CPR * 8) + tid]; }
-      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * N;
-      pr[n0 + tid] = t0;
-      pr[N + n0 + tid] = t1;
-    }
-  }
-}
-
 // the bf16 epilogue of a BM x BN tile staged through LDS (shared with the forms of igemm_fwd_dma_kernel that inline it):
 // compute waves park bias + activation of their accumulators as bf16 rows, then every thread moves whole 16-byte
 // chunks of pixel rows (mask multiply, column partials: see igemm_fwd_dma_kernel)
@@ -1179,10 +1084,6 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
   }
   __syncthreads();
   const float mlow = mask_low(mmode, leak);
-  if (args.col_partial) {
-    store_tile_with_col_partials<BM, BN, NTHR>(sE, sPix, reinterpret_cast<float*>(smem + BM * PE + BM * 8), sBias, tid, m0, n0, M, tile_m, args, cl);
-    return;
-  }
   constexpr int NIT = (BM * CPR + NTHR - 1) / NTHR;
   long long pp[NIT];
   bf16x8 mv[NIT];
@@ -1215,11 +1116,41 @@ __device__ __forceinline__ void staged_epilogue_bf16(f32x4 (&acc)[TM][TN], char*
     if (mmode != TDG_MASK_NONE) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * ((float)mv[it][e] > 0.f ? 1.f : mlow));
+      if (args.col_partial) *reinterpret_cast<bf16x8*>(sE + row * PE + cc * 16) = v;
     }
     if (n + 8 <= N) {
       *reinterpret_cast<bf16x8*>(out + p + n) = v;
     } else {
       *reinterpret_cast<bf16x4*>(out + p + n) = bf16x4{v[0], v[1], v[2], v[3]};
+    }
+  }
+  if (args.col_partial) {
+    constexpr int G = NTHR / BN > 0 ? NTHR / BN : 1;
+    float* sRed = reinterpret_cast<float*>(smem + BM * PE + BM * 8);
+    __syncthreads();
+    const int mlim = args.col_images > 0 ? min(M, args.col_images * cl.GH * cl.GW * (cl.nbh * cl.nbw > 1 ? cl.nbh * cl.nbw : 1)) : M;
+    const int rows_valid = max(0, min(BM, mlim - m0));
+    const int col = tid % BN, grp = tid / BN;
+    const bool bnm = args.col_mode == TDG_COL_BN;
+    if (grp < G) {
+      const float piv = bnm ? sBias[col] : 0.f;
+      float s0 = 0.f, s1 = 0.f;
+      for (int r = grp; r < rows_valid; r += G) {
+        const float v = (float)*reinterpret_cast<const bf16_t*>(sE + r * PE + col * 2) - piv;
+        s0 += v;
+        s1 += v * v;
+      }
+      sRed[(grp * 2 + 0) * BN + col] = s0;
+      sRed[(grp * 2 + 1) * BN + col] = s1;
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < N) {
+      float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { t0 += sRed[(g * 2 + 0) * BN + tid]; t1 += sRed[(g * 2 + 1) * BN + tid]; }
+      float* pr = args.col_partial + (size_t)(blockIdx.z * args.ntiles_m_max + tile_m) * 2 * N;
+      pr[n0 + tid] = t0;
+      pr[N + n0 + tid] = t1;
     }
   }
 }
