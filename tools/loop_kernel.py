@@ -1,5 +1,5 @@
 """Diagnostics: one kernel in a loop for a stated time (for power / clock / throttle sampling beside it: tools/power_probe.sh).
-usage: python tools/loop_kernel.py fwd|bwd_data|wgrad|matmul SECONDS [c2|c3] [masked|maskonly|colonly]  ->  prints launches, ms per launch, TFLOP/s
+usage: python tools/loop_kernel.py fwd|bwd_data|wgrad|matmul SECONDS [c2|c3|e2] [masked|maskonly|colonly]  ->  prints launches, ms per launch, TFLOP/s
 (c3 = the critic's 8x8x400 -> 4x4x800 conv on 1536 images, the default; c2 = 16x16x200 -> 8x8x400; `masked`: backward-data with the
 lrelu derivative mask and the bias-gradient column partials of the training step's launch)"""
 import importlib
@@ -21,7 +21,8 @@ def main(what, seconds, layer='c3', masked=False):
         b = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
         fn, fl = (lambda: torch.matmul(a, b)), 2.0 * 8192 ** 3
     else:
-        n, h, w, cin, cout, k, s = (1536, 8, 8, 400, 800, 5, 2) if layer == 'c3' else (1536, 16, 16, 200, 400, 5, 2)   # the critic's c3 / c2 on [x | g | x_hat]
+        n, h, w, cin, cout, k, s = {'c3': (1536, 8, 8, 400, 800, 5, 2), 'c2': (1536, 16, 16, 200, 400, 5, 2),    # the critic's c3 / c2 on [x | g | x_hat]
+                                    'e2': (64, 128, 128, 64, 128, 4, 2)}[layer]                                   # pix2pix e2 (its backward-data: 64 columns, 8 K steps per class)
         big, small = K.Act(n, h, w, cin, K.BF16, dev), K.Act(n, h // 2, w // 2, cout, K.BF16, dev)
         big.buf.copy_(torch.randn_like(big.buf.float()).to(big.buf.dtype))
         small.buf.copy_(torch.randn_like(small.buf.float()).to(small.buf.dtype))
