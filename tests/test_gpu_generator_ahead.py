@@ -151,7 +151,7 @@ def test_iteration_with_look_ahead_equals_pass_per_step(use_graphs):
                 out = rep.losses()
         torch.cuda.synchronize()
         if use_graphs:
-            assert ('g_ahead' in rep._graphs) == ahead and ('d_grads+ahead' in rep._graphs) == ahead
+            assert ('g_ahead' in rep._graphs) == ahead and ('d_step+ahead' in rep._graphs) == ahead and ('d_step' in rep._graphs) != ahead
         finals.append((v0, rep.variables(), out))
         del rep, sess
         torch.cuda.empty_cache()
