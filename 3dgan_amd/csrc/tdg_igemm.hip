@@ -2712,11 +2712,58 @@ __global__ void __launch_bounds__(256) pack_filter_kernel(const PackArgs a) {
   pack_tiles<T>(a, blockIdx.x, blockIdx.y, tile);
 }
 
+// merged filter of bwd_fused_kernel from the f32 master [kh][kw][c][k]
+struct FusedPackArgs {
+  const float* w;
+  bf16_t* out;
+  int C, K, KH, KW, pad_t, pad_l;
+  int nhm, nwm, dh_min, dw_min, KP, wpitch;
+};
+__device__ __forceinline__ void pack_fused_elem(const FusedPackArgs& a, int i) {
+  if (i >= 16 * a.wpitch) return;
+  const int col = i / a.wpitch, r = i - col * a.wpitch;
+  float v = 0.f;
+  const int cls = col / a.C, c = col - cls * a.C;
+  const int tap = r / a.KP, k = r - tap * a.KP;
+  if (cls < 4 && tap < a.nhm * a.nwm && k < a.K) {
+    const int th = tap / a.nwm, tw = tap - th * a.nwm;
+    const int kh = (cls >> 1) + a.pad_t - 2 * (a.dh_min + th), kw = (cls & 1) + a.pad_l - 2 * (a.dw_min + tw);
+    if (kh >= 0 && kh < a.KH && kw >= 0 && kw < a.KW) v = a.w[(((size_t)kh * a.KW + kw) * a.C + c) * a.K + k];
+  }
+  a.out[i] = (bf16_t)v;
+}
+__global__ void __launch_bounds__(256) pack_fused_kernel(const FusedPackArgs a) { pack_fused_elem(a, blockIdx.x * 256 + threadIdx.x); }
+
+// filter of thin_fwd_kernel from the f32 master [kh][kw][c][k]: rows n (zero beyond N), k = tap * C + c
+struct ThinPackArgs {
+  const float* w;
+  bf16_t* out;
+  int C, N, taps, Kp, WP, rows;
+  int tile_rows, tile_cols;   // filter rows staged per column tile / output columns of a tile (224 / 208 or 64 / 64)
+};
+__device__ __forceinline__ void pack_thin_elem(const ThinPackArgs& a, int i) {
+  if (i >= a.rows * a.WP) return;
+  const int r = i / a.WP, k = i - r * a.WP;
+  const int n = (r / a.tile_rows) * a.tile_cols + (r % a.tile_rows);     // row r of tile t = r / tile_rows is output column t * tile_cols + r % tile_rows
+  float v = 0.f;
+  if ((r % a.tile_rows) < a.tile_cols && n < a.N && k < a.taps * a.C) {
+    const int tap = k / a.C, c = k - tap * a.C;
+    v = a.w[((size_t)tap * a.C + c) * a.N + n];
+  }
+  a.out[i] = (bf16_t)v;
+}
+__global__ void __launch_bounds__(256) pack_thin_kernel(const ThinPackArgs a) { pack_thin_elem(a, blockIdx.x * 256 + threadIdx.x); }
+
 // several packing jobs in one launch: block b belongs to the job j with start[j] <= b < start[j+1]
 #define PACK_MULTI_MAX 32
+// ... behind them thin_blocks blocks of the thin-input filter and fused_blocks blocks of the fused-class backward-data filter of the same
+// network (one element per thread; they were two launches of ~5 us each per packing call)
 struct PackMultiArgs {
   int njobs;
   int start[PACK_MULTI_MAX + 1];
+  int thin_blocks, fused_blocks;
+  ThinPackArgs thin;
+  FusedPackArgs fused;
   PackArgs job[PACK_MULTI_MAX];
 };
 static_assert(sizeof(PackMultiArgs) <= 4096, "kernel argument block");
@@ -2724,6 +2771,13 @@ static_assert(sizeof(PackMultiArgs) <= 4096, "kernel argument block");
 template <typename T>
 __global__ void __launch_bounds__(256) pack_multi_kernel(const PackMultiArgs m) {
   __shared__ float tile[PACK_TK][33];
+  const int ntile = m.start[m.njobs];
+  if ((int)blockIdx.x >= ntile) {
+    const int b = blockIdx.x - ntile;
+    if (b < m.thin_blocks) pack_thin_elem(m.thin, b * 256 + threadIdx.x);
+    else pack_fused_elem(m.fused, (b - m.thin_blocks) * 256 + threadIdx.x);
+    return;
+  }
   int j = 0;
   while (j + 1 < m.njobs && (int)blockIdx.x >= m.start[j + 1]) ++j;
   const PackArgs& a = m.job[j];
@@ -3050,28 +3104,6 @@ __global__ void __launch_bounds__(256) conv_n1_fwd_kernel(const ConvN1Args a) {
     static_cast<T*>(a.y)[(size_t)m * a.Cso] = from_f32<T>(apply_act(s + (a.bias ? a.bias[0] : 0.f), a.act, a.leak));
 }
 
-// merged filter of bwd_fused_kernel from the f32 master [kh][kw][c][k]
-struct FusedPackArgs {
-  const float* w;
-  bf16_t* out;
-  int C, K, KH, KW, pad_t, pad_l;
-  int nhm, nwm, dh_min, dw_min, KP, wpitch;
-};
-__global__ void __launch_bounds__(256) pack_fused_kernel(const FusedPackArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 16 * a.wpitch) return;
-  const int col = i / a.wpitch, r = i - col * a.wpitch;
-  float v = 0.f;
-  const int cls = col / a.C, c = col - cls * a.C;
-  const int tap = r / a.KP, k = r - tap * a.KP;
-  if (cls < 4 && tap < a.nhm * a.nwm && k < a.K) {
-    const int th = tap / a.nwm, tw = tap - th * a.nwm;
-    const int kh = (cls >> 1) + a.pad_t - 2 * (a.dh_min + th), kw = (cls & 1) + a.pad_l - 2 * (a.dw_min + tw);
-    if (kh >= 0 && kh < a.KH && kw >= 0 && kw < a.KW) v = a.w[(((size_t)kh * a.KW + kw) * a.C + c) * a.K + k];
-  }
-  a.out[i] = (bf16_t)v;
-}
-
 // ============================================================================================
 // Forward conv of a THIN input (C <= 4 channels: the discriminator's / encoder's first layer on images).  The
 // implicit-GEMM kernels see such an input as 8-channel pixels, i.e. K = taps x 8 padded to 64s (75 real of 256 for
@@ -3264,26 +3296,6 @@ __global__ void __launch_bounds__(256, 2) thin_fwd_kernel(const ThinFwdArgs a) {
     }
   }
 #endif
-}
-
-// filter of thin_fwd_kernel from the f32 master [kh][kw][c][k]: rows n (zero beyond N), k = tap * C + c
-struct ThinPackArgs {
-  const float* w;
-  bf16_t* out;
-  int C, N, taps, Kp, WP, rows;
-  int tile_rows, tile_cols;   // filter rows staged per column tile / output columns of a tile (224 / 208 or 64 / 64)
-};
-__global__ void __launch_bounds__(256) pack_thin_kernel(const ThinPackArgs a) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.rows * a.WP) return;
-  const int r = i / a.WP, k = i - r * a.WP;
-  const int n = (r / a.tile_rows) * a.tile_cols + (r % a.tile_rows);     // row r of tile t = r / tile_rows is output column t * tile_cols + r % tile_rows
-  float v = 0.f;
-  if ((r % a.tile_rows) < a.tile_cols && n < a.N && k < a.taps * a.C) {
-    const int tap = k / a.C, c = k - tap * a.C;
-    v = a.w[((size_t)tap * a.C + c) * a.N + n];
-  }
-  a.out[i] = (bf16_t)v;
 }
 
 // ============================================================================================
@@ -4159,23 +4171,29 @@ static int launch_pack_one(const PackArgs& a, int dtype, hipStream_t s) {
   return TDG_OK;
 }
 
+static void fill_pack_fused(const TdgConvDesc* d, const FusedPlan& fp, const float* w, void* packed, FusedPackArgs* a) {
+  a->w = w;
+  a->out = static_cast<bf16_t*>(packed);
+  a->C = d->c; a->K = d->k; a->KH = d->kh; a->KW = d->kw; a->pad_t = d->pad_t; a->pad_l = d->pad_l;
+  a->nhm = fp.nhm; a->nwm = fp.nwm; a->dh_min = fp.dh_min; a->dw_min = fp.dw_min; a->KP = fp.KP; a->wpitch = fp.wpitch;
+}
 static int launch_pack_fused(const TdgConvDesc* d, const FusedPlan& fp, const float* w, void* packed, hipStream_t s) {
   FusedPackArgs a;
-  a.w = w;
-  a.out = static_cast<bf16_t*>(packed);
-  a.C = d->c; a.K = d->k; a.KH = d->kh; a.KW = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
-  a.nhm = fp.nhm; a.nwm = fp.nwm; a.dh_min = fp.dh_min; a.dw_min = fp.dw_min; a.KP = fp.KP; a.wpitch = fp.wpitch;
+  fill_pack_fused(d, fp, w, packed, &a);
   hipLaunchKernelGGL(pack_fused_kernel, dim3(tdg_ceil_div(16 * fp.wpitch, 256)), dim3(256), 0, s, a);
   TDG_HIP_LAUNCH_CHECK("pack_filter_bwd(fused)");
   return TDG_OK;
 }
 
+static void fill_pack_thin(const TdgConvDesc* d, const ThinPlan& tp, const float* w, void* packed, ThinPackArgs* a) {
+  a->w = w;
+  a->out = static_cast<bf16_t*>(packed);
+  a->C = d->c; a->N = d->k; a->taps = d->kh * d->kw; a->Kp = tp.Kp; a->WP = tp.WP; a->rows = tp.rows;
+  a->tile_rows = tp.NC == 208 ? 224 : 64; a->tile_cols = tp.NC;
+}
 static int launch_pack_thin(const TdgConvDesc* d, const ThinPlan& tp, const float* w, void* packed, hipStream_t s) {
   ThinPackArgs a;
-  a.w = w;
-  a.out = static_cast<bf16_t*>(packed);
-  a.C = d->c; a.N = d->k; a.taps = d->kh * d->kw; a.Kp = tp.Kp; a.WP = tp.WP; a.rows = tp.rows;
-  a.tile_rows = tp.NC == 208 ? 224 : 64; a.tile_cols = tp.NC;
+  fill_pack_thin(d, tp, w, packed, &a);
   hipLaunchKernelGGL(pack_thin_kernel, dim3(tdg_ceil_div((long long)tp.rows * tp.WP, 256)), dim3(256), 0, s, a);
   TDG_HIP_LAUNCH_CHECK("pack_filter_fwd(thin)");
   return TDG_OK;
@@ -4219,14 +4237,17 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
   static PackMultiArgs m;                       // 4 KB: built on the host, passed by value at launch (one host thread per GPU)
   m.njobs = 0;
   m.start[0] = 0;
+  m.thin_blocks = m.fused_blocks = 0;
   auto flush = [&]() -> int {
-    if (m.njobs == 0) return TDG_OK;
+    const int nb = m.start[m.njobs] + m.thin_blocks + m.fused_blocks;
+    if (nb == 0) return TDG_OK;
     if (dtype == TDG_BF16)
-      hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(m.start[m.njobs]), dim3(256), 0, (hipStream_t)stream, m);
+      hipLaunchKernelGGL(pack_multi_kernel<bf16_t>, dim3(nb), dim3(256), 0, (hipStream_t)stream, m);
     else
-      hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(m.start[m.njobs]), dim3(256), 0, (hipStream_t)stream, m);
+      hipLaunchKernelGGL(pack_multi_kernel<float>, dim3(nb), dim3(256), 0, (hipStream_t)stream, m);
     TDG_HIP_LAUNCH_CHECK("pack_filters");
     m.njobs = 0;
+    m.thin_blocks = m.fused_blocks = 0;
     return TDG_OK;
   };
   auto push = [&](const PackArgs& a) -> int {
@@ -4248,8 +4269,13 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
     if (jobs[j].packed_fwd) {
       ThinPlan tp;
       if (plan_fwd_thin(d, &tp)) {
-        rc = launch_pack_thin(d, tp, jobs[j].w, jobs[j].packed_fwd, (hipStream_t)stream);
-        if (rc) return rc;
+        if (m.thin_blocks == 0) {                              // rides in the multi-job launch (the first one of a call)
+          fill_pack_thin(d, tp, jobs[j].w, jobs[j].packed_fwd, &m.thin);
+          m.thin_blocks = tdg_ceil_div((long long)tp.rows * tp.WP, 256);
+        } else {
+          rc = launch_pack_thin(d, tp, jobs[j].w, jobs[j].packed_fwd, (hipStream_t)stream);
+          if (rc) return rc;
+        }
       } else {
         PackArgs a;
         build_pack_fwd(d, jobs[j].w, jobs[j].packed_fwd, &a);
@@ -4266,8 +4292,13 @@ int tdg_pack_filters(const TdgPackJob* jobs, int n_jobs, void* stream) {
         rc = push(a);
         if (rc) return rc;
       } else if (plan_bwd_fused(d, &fp)) {
-        rc = launch_pack_fused(d, fp, jobs[j].w, jobs[j].packed_bwd, (hipStream_t)stream);
-        if (rc) return rc;
+        if (m.fused_blocks == 0) {
+          fill_pack_fused(d, fp, jobs[j].w, jobs[j].packed_bwd, &m.fused);
+          m.fused_blocks = tdg_ceil_div(16 * fp.wpitch, 256);
+        } else {
+          rc = launch_pack_fused(d, fp, jobs[j].w, jobs[j].packed_bwd, (hipStream_t)stream);
+          if (rc) return rc;
+        }
       } else {
         PackArgs a[IG_MAX_CLASSES];
         const int n = build_pack_bwd(d, jobs[j].w, jobs[j].packed_bwd, a);
