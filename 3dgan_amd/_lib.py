@@ -86,6 +86,7 @@ SIGNATURES = {
     'tdg_sumsq': (_i, [_i, _vp, _sz, _vp, _f, _vp, _sz, _vp]),
     'tdg_reduce_workspace_bytes': (_sz, [_sz]),
     'tdg_mean_f32': (_i, [_vp, _i, _vp, _vp]),
+    'tdg_sum_f32': (_i, [_vp, _i, _vp, _f, _vp]),
     'tdg_mean_segments_f32': (_i, [_vp, _i, _i, _vp, _vp]),
     'tdg_gan_logloss': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     'tdg_p2p_xent': (_i, [_i, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     'tdg_dropout': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp]),
     'tdg_l1_loss': (_i, [_i, _vp, _vp, _i, _i, _i, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     'tdg_gp_scalars': (_i, [_vp, _f, _vp, _vp]),
+    'tdg_gp_sumsq': (_i, [_i, _vp, _sz, _vp, _f, _vp, _vp, _sz, _vp]),
     'tdg_scale_by_dev': (_i, [_i, _vp, _sz, _vp, _vp, _vp]),
     'tdg_fill_f32': (_i, [_vp, _sz, _f, _vp]),
     'tdg_bias_grad': (_i, [_i, _vp, _i, _i, _i, _vp, _f, _vp, _sz, _vp]),

@@ -1100,7 +1100,8 @@ extern "C" size_t tdg_reduce_workspace_bytes(size_t) { return RED_BLOCKS * sizeo
 // acc = beta * acc + sum x^2: per-block partials, summed by the block that arrives last in a fixed order (deterministic)
 template <typename T>
 __global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict__ x, size_t n, float* __restrict__ partial,
-                                                           float* __restrict__ acc, float beta) {
+                                                           float* __restrict__ acc, float beta, float gp_lambda = 0.f,
+                                                           float* __restrict__ gp_scal = nullptr) {
   __shared__ float sh[4];
   float s = 0.f;
   constexpr int VW = 16 / (int)sizeof(T);
@@ -1136,7 +1137,15 @@ __global__ void __launch_bounds__(256) sumsq_partial_kernel(const T* __restrict_
   float t = 0.f;
   for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += partial[i];
   t = block_sum256(t, sh);
-  if (threadIdx.x == 0) acc[0] = (beta != 0.f ? beta * acc[0] : 0.f) + t;
+  if (threadIdx.x == 0) {
+    const float ss = (beta != 0.f ? beta * acc[0] : 0.f) + t;
+    acc[0] = ss;
+    if (gp_scal) {                                          // tdg_gp_sumsq: the penalty scalars of gp_scalars_kernel from the same launch
+      const float sl = sqrtf(ss);
+      gp_scal[0] = (sl - 1.f) * (sl - 1.f);
+      gp_scal[1] = gp_lambda * 2.f * (sl - 1.f) / sl;
+    }
+  }
 }
 // out[seg] = beta * out[seg] + scale * sum(x[seg * seglen ...]) : one block per segment
 __global__ void __launch_bounds__(256) reduce_final_kernel(const float* __restrict__ partial, int np, float* __restrict__ acc,
@@ -1160,10 +1169,30 @@ extern "C" int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float b
   TDG_HIP_LAUNCH_CHECK("sumsq");
   return TDG_OK;
 }
+// tdg_sumsq(beta = 0) + tdg_gp_scalars in one launch: sumsq[0] = sum x^2, scal[0] = (sqrt(sumsq) - 1)^2, scal[1] = lambda * 2 (s - 1) / s
+extern "C" int tdg_gp_sumsq(int dtype, const void* x, size_t n, float* sumsq, float lambda, float* scal, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  TDG_CHECK_ARG(x && sumsq && scal && workspace && n > 0, "tdg_gp_sumsq: bad argument");
+  if (workspace_bytes < RED_BLOCKS * sizeof(float)) { tdg_set_error("tdg_gp_sumsq: workspace too small"); return TDG_EWORKSPACE; }
+  TDG_TICKET_STREAM("tdg_gp_sumsq", stream);
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(sumsq_partial_kernel<T>, dim3(RED_BLOCKS), dim3(256), 0, (hipStream_t)stream, static_cast<const T*>(x),
+                       n, static_cast<float*>(workspace), sumsq, 0.f, lambda, scal);
+  })
+  TDG_HIP_LAUNCH_CHECK("gp_sumsq");
+  return TDG_OK;
+}
 extern "C" int tdg_mean_segments_f32(const float* x, int nseg, int seglen, float* out, void* stream) {
   TDG_CHECK_ARG(x && out && nseg > 0 && nseg <= 65535 && seglen > 0, "tdg_mean_segments_f32: bad argument");
   hipLaunchKernelGGL(reduce_final_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, x, seglen, out, 0.f, 1.f / (float)seglen);
   TDG_HIP_LAUNCH_CHECK("mean_segments_f32");
+  return TDG_OK;
+}
+// out[0] = beta * out[0] + sum x  (one block: the bias gradient of a one-column dense layer = the sum of its seeds)
+extern "C" int tdg_sum_f32(const float* x, int n, float* out, float beta, void* stream) {
+  TDG_CHECK_ARG(x && out && n > 0, "tdg_sum_f32: bad argument");
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, out, beta, 1.f);
+  TDG_HIP_LAUNCH_CHECK("sum_f32");
   return TDG_OK;
 }
 extern "C" int tdg_mean_f32(const float* x, int n, float* out, void* stream) {

@@ -523,7 +523,7 @@ class SeqNet:
                 if want_params and qn > 0:
                     K.colsum_weighted(self.ws, self.dtype, L.inp.ptr(q0), qn, cols, cols, _sub(L.seed, q0, qn),
                                       g(L.wname), beta)
-                    K.colsum_weighted(self.ws, K.F32, K.ptr(L.seed, 4 * q0), qn, 1, 1, None, g(L.bname), beta)
+                    _lib.call('tdg_sum_f32', K.ptr(L.seed, 4 * q0), qn, K.ptr(g(L.bname)), beta, K.stream())      # (one launch)
                 if need_in:
                     _lib.call('tdg_rowouter', self.dtype, K.ptr(L.seed, 4 * d0), K.ptr(self.store[L.wname]), dn, cols,
                               mmode, mleak, msrc.ptr(dimg * below.rpi) if msrc is not None else None, L.gin.ptr(d0), K.stream())

@@ -275,8 +275,9 @@ class GanReplica(engine.GraphRunner):
                       u.ptr(0), K.stream())
             _lib.call('tdg_mean_f32', K.ptr(self._pen_rows), B, K.ptr(self.scal, 4 * self.S_GP), K.stream())
             return
-        K.sumsq(self.ws, self.sess.dtype, self.D.dx.ptr(slot * B), B * self.img_elems, self.scal[self.S_SUMSQ:])
-        _lib.call('tdg_gp_scalars', K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA, K.ptr(self.scal, 4 * self.S_GP), K.stream())
+        w = self.ws.ensure(4096)                                      # sum of squares and the penalty scalars in one launch
+        _lib.call('tdg_gp_sumsq', self.sess.dtype, self.D.dx.ptr(slot * B), B * self.img_elems, K.ptr(self.scal, 4 * self.S_SUMSQ), GP_LAMBDA,
+                  K.ptr(self.scal, 4 * self.S_GP), K.ptr(w), w.numel(), K.stream())
         if tangent_seed:
             _lib.call('tdg_scale_by_dev', self.sess.dtype, self.D.dx.ptr(slot * B), B * self.img_elems,
                       K.ptr(self.scal, 4 * self.S_GPCOEF), self.D.tan_in.ptr(0), K.stream())

@@ -246,6 +246,8 @@ int tdg_sumsq(int dtype, const void* x, size_t n, float* acc, float beta, void* 
 size_t tdg_reduce_workspace_bytes(size_t n);
 /* out[0] = mean(x[0:n]) f32 input (tf.reduce_mean of D outputs, models/gan.py:196-204) */
 int tdg_mean_f32(const float* x, int n, float* out, void* stream);
+/* out[0] = beta * out[0] + sum of n floats, one launch (the bias gradient of a dense layer with one output: ops/layers.py:56-57) */
+int tdg_sum_f32(const float* x, int n, float* out, float beta, void* stream);
 /* out[s] = mean(x[s*seglen : (s+1)*seglen]) for s < nseg, one launch (the means of D(x) and D(g), :196-197) */
 int tdg_mean_segments_f32(const float* x, int nseg, int seglen, float* out, void* stream);
 /* Vanilla-GAN losses on post-sigmoid scores (models/gan.py:193-194) and their gradients w.r.t. the LOGITS:
@@ -295,6 +297,9 @@ int tdg_dropout(int dtype, void* y, int rows, int c, int ycs, const float* u, fl
 /* GP scalars from sumsq (device-resident, no host sync): slopes = sqrt(ss);
  * scal[0] = penalty = (slopes-1)^2 ; scal[1] = lambda * 2*(slopes-1)/slopes            */
 int tdg_gp_scalars(const float* sumsq, float lambda, float* scal, void* stream);
+/* tdg_sumsq (beta = 0) and tdg_gp_scalars in one launch (models/gan.py:229-230: slopes over the WHOLE batch tensor, penalty) */
+int tdg_gp_sumsq(int dtype, const void* x, size_t n, float* sumsq, float lambda, float* scal, void* workspace,
+                 size_t workspace_bytes, void* stream);
 /* out = coef[0] * in   (u = d penalty / d v, coefficient read from device memory) */
 int tdg_scale_by_dev(int dtype, const void* in, size_t n, const float* coef, void* out, void* stream);
 /* --gp_per_sample (SURVEY App. C-4 opt-in: the reference takes ONE norm over the whole batch tensor, models/gan.py:229):
